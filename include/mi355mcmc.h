@@ -1,0 +1,169 @@
+/* mi355mcmc.h - C ABI of libmi355mcmc.so: the MI355X (gfx950) implementation of the
+ * Metropolis-Hastings likelihood hot path of defjaf/MCMC.
+ *
+ * The reference is pure Python and has no FFI: its "operator API" is the duck-typed
+ * protocol between MCMC.MCMC and its like / model / prop objects.
+ * Each entry point below names the reference call (file:line under the reference tree)
+ * whose batched equivalent it computes; mcmc_amd/ (Python, ctypes) keeps the reference's
+ * class names and method signatures on top of it.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; mi355_last_error() then returns a
+ *    thread-local human-readable message.  No entry point ever falls back to a CPU path.
+ *  - "host" pointers are caller-owned host memory, "dev" pointers are device memory on the
+ *    context's GPU (e.g. torch tensor data_ptr()).  All arrays are FP64 unless typed.
+ *  - a context is bound to one GPU and one HIP stream; it is not thread-safe.  Calls are
+ *    synchronous on return unless the name ends in _async.
+ *  - chain index n = s*C + c (source-major); parameter vectors are "flat" (unpackaged).
+ */
+#ifndef MI355MCMC_H
+#define MI355MCMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+typedef struct mi355_ctx mi355_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* seed keys the Philox4x32-10 streams that replace numpy's global MT19937
+ * (MCMC/Proposal.py:3,64,151; MCMC/MCMC.py:37,113,264). */
+int mi355_init(int device, uint64_t seed, mi355_ctx** out);
+void mi355_free(mi355_ctx* ctx);
+const char* mi355_last_error(void);
+int mi355_abi_version(void);
+/* the HIP stream (hipStream_t) all kernels of this context are launched on */
+void* mi355_stream(mi355_ctx* ctx);
+int mi355_sync(mi355_ctx* ctx);
+
+/* ---- submmSED models: MCMC/submmSED/model.py ------------------------------------------- */
+enum mi355_sed_model_id {
+  MI355_SED_M1N = 0,        /* submmModel1_normalized            model.py:529-616  (A, beta, T)            */
+  MI355_SED_M1N_LOGA = 1,   /* submmModel1_normalized_logA       model.py:748-769  (log10 A, beta, T)      */
+  MI355_SED_M2N = 2,        /* submmModel2_normalized            model.py:363-468  (A1,b1,T1,A2,b2,T2)     */
+  MI355_SED_M2N_LOGA = 3,   /* submmModel2_normalized_logA       model.py:470-526                           */
+  MI355_SED_M1 = 4,         /* submmModel1 + SEDLikelihood1      model.py:218-279, likelihood.py:93-123    */
+  MI355_SED_M2 = 5,         /* submmModel2 + SEDLikelihood2      model.py:130-215, likelihood.py:18-88     */
+  MI355_SED_THICK = 6,      /* submmModel1_opticallythick        model.py:620-705  (A, beta, T, nu0)       */
+  MI355_SED_THICK_LOGA = 7, /* submmModel1_opticallythick_logA   model.py:709-746  (inherits the plain
+                               greybody at(): nu0 enters the prior only - reproduced)                      */
+  MI355_SED_NMODEL = 8
+};
+
+/* Module-level constants of model.py:55-61,638 captured per context ("compile-time" flags
+ * of the reference become fields here). */
+typedef struct {
+  int32_t model;              /* enum mi355_sed_model_id */
+  int32_t nparam;             /* must equal the model's parameter count (checked)  */
+  double h_over_k;            /* 0.04799237 K/GHz   model.py:55 */
+  double nu_b;                /* 1000 GHz           model.py:57 */
+  double prefac;              /* 1e-9               model.py:56 */
+  double Tmin, Tmax;          /* 3, 100 K           model.py:59 */
+  double bmin, bmax;          /* 0, 3               model.py:61 */
+  double nu_rescale;          /* 1000               model.py:638 */
+} mi355_sed_model;
+
+/* Default constants of the reference for `model`. */
+int mi355_sed_model_default(int32_t model, mi355_sed_model* out);
+int mi355_sed_nparam(int32_t model);
+
+/* Load a catalogue of S sources (submmData / GaussianData: submmSED/data.py:30-45,
+ * GaussianData.py:13-28).  nb[s] <= nb_max photometric bands per source; nu (rest-frame
+ * GHz), d (flux) and sig are [S, nb_max] row-major, entries past nb[s] ignored.
+ * Upper limits are encoded by the caller as d=0, sig=flux (data.py:233-237). */
+int mi355_sed_load(mi355_ctx* ctx, const mi355_sed_model* model, int64_t S, int32_t nb_max,
+                   const int32_t* nb, const double* nu, const double* d, const double* sig);
+
+/* like.lnLike(theta) (Likelihood.py:99-105 -> submmSED/likelihood.py:141-155, :99-110,
+ * :35-74) for sources [s0, s0+ns) x C parameter vectors each.
+ * theta: host [ns, C, P]; lnL: host [ns, C]; derived (nullable): host [ns, C, 2], the
+ * maximum-likelihood amplitudes of SEDLikelihood1/2.getDerived (likelihood.py:77-88,113-123),
+ * NaN-filled for the explicit-amplitude models. */
+int mi355_sed_lnlike(mi355_ctx* ctx, int64_t s0, int64_t ns, int32_t C, const double* theta,
+                     double* lnL, double* derived);
+/* Same on device memory, no copies: theta_dev is parameter-major [P, ns*C], lnL_dev [ns*C],
+ * derived_dev nullable [2, ns*C].  Asynchronous on the context stream. */
+int mi355_sed_lnlike_dev_async(mi355_ctx* ctx, int64_t s0, int64_t ns, int32_t C,
+                               const double* theta_dev, double* lnL_dev, double* derived_dev);
+/* model.prior(*theta) (model.py prior classmethods) and model.package(theta)
+ * (model.py:192-196,439-443,510-514) for n flat vectors: host [n,P] -> prior[n], packaged[n,P]
+ * (either output nullable). */
+int mi355_sed_prior_package(mi355_ctx* ctx, int64_t n, const double* theta, double* prior,
+                            double* packaged);
+
+/* ---- Metropolis-Hastings: MCMC/MCMC.py, MCMC/Proposal.py -------------------------------- */
+/* Create C chains per loaded source (N = S*C chains) = N instances of
+ * MCMC.MCMC(like, startProposal=sigma, startParams=theta0, doBlock=nblock>0) (MCMC.py:61-134).
+ *  theta0 : host [P] (theta0_per_chain=0) or [S,C,P] (=1)
+ *  sigma  : host [P] (sigma_per_chain=0) or [S,C,P] (=1); sigma=0 fixes a parameter
+ *  param_blocks: host [P] block id per parameter (model.paramBlocks), nblock = model.nBlock;
+ *           nblock=0 means doBlock=False (all parameters move every step)
+ *  randomize_start: 1 = setStart(random=True) (MCMC.py:151-159): redraw theta0 + sigma*N(0,1)
+ *           over all parameters until prior>0, with the context's Philox start stream;
+ *           0 = start exactly at theta0 (the injected-draw parity path; prior must be >0). */
+int mi355_mh_init(mi355_ctx* ctx, int32_t C, const double* theta0, int32_t theta0_per_chain,
+                  const double* sigma, int32_t sigma_per_chain, const int32_t* param_blocks,
+                  int32_t nblock, int32_t randomize_start);
+
+/* MC_append(nsteps) for every chain (MCMC.py:196-221 -> sample() :225-286 ->
+ * getNewParams Proposal.py:127-164).  State stays in HBM between calls.
+ *  thin : keep every thin-th step in the trace buffer (0 = no trace)
+ *  inj_normals  (nullable) host [nsteps, N, P]: the P normals Proposal.py:151 draws per step
+ *  inj_uniforms (nullable) host [nsteps, N]   : the uniform of MCMC.py:264 for that step
+ *  (both or neither; with them the chain is draw-for-draw the reference's). */
+int mi355_mh_run(mi355_ctx* ctx, int64_t nsteps, int32_t thin, const double* inj_normals,
+                 const double* inj_uniforms);
+
+/* mean(burn=1), stdev(burn=1)**2 (ddof=0, MCMC.py:290-307) over the steps run since the last
+ * init/adapt, naccept (MCMC.py:179,269), per-block accept counts (:181,271) and the current
+ * lnPr / position.  Host outputs, all nullable: mean,var,theta [S,C,P]; naccept,lnPr [S,C];
+ * accept [S,C,nblock]. */
+int mi355_mh_moments(mi355_ctx* ctx, double* mean, double* var, int64_t* naccept,
+                     int64_t* accept, double* lnPr, double* theta);
+/* Philox stream position of the context: which=0 the global step counter (normal index =
+ * step*npn + rank, uniform index = step), which=1 the stage counter (number of init/adapt calls
+ * so far; keys the start-randomisation stream).  Counter-based draws make a resumed run exact:
+ * restore both with mi355_mh_set_stream_pos before mi355_mh_init. */
+int64_t mi355_mh_stream_pos(mi355_ctx* ctx, int32_t which);
+int mi355_mh_set_stream_pos(mi355_ctx* ctx, int64_t step, int64_t stage);
+/* Number of steps accumulated in the moments, and kept trace rows. */
+int64_t mi355_mh_nsamples(mi355_ctx* ctx);
+int64_t mi355_mh_ntrace(mi355_ctx* ctx);
+/* Trace of the last mi355_mh_run: samples host [nkeep,S,C,P], lnPr [nkeep,S,C],
+ * accepted [nkeep,S,C] (MCMC.samples / .lnPr / .accepted rows, MCMC.py:217-219). */
+int mi355_mh_trace(mi355_ctx* ctx, double* samples, double* lnPr, uint8_t* accepted);
+
+/* newMCMC(burn=1, fac, random=random_restart, noCorrelations=True) for every chain
+ * (MCMC.py:343-413): restart at package(mean) [+ N(0,1)*stdev], sigma = package(fac*stdev)
+ * (fac<=0 means 2.4/sqrt(nparam), :379-380), counters and moments reset, start randomised
+ * as in mi355_mh_init(randomize_start=1). */
+int mi355_mh_adapt(mi355_ctx* ctx, double fac, int32_t random_restart);
+
+/* Fill host buffers with the context's Philox streams (diagnostic; lets a test replay the
+ * free-running draws through the oracle): normals [nsteps, N, npn], uniforms [nsteps, N]
+ * for steps [step0, step0+nsteps) of chains [0,N). */
+int mi355_rng_dump(mi355_ctx* ctx, int64_t step0, int64_t nsteps, int64_t N, int32_t npn,
+                   double* normals, double* uniforms);
+
+/* ---- Gelman-Rubin: MCMC/convergence.py:58-87 -------------------------------------------- */
+/* Per-source partial sums over this context's C chains, for an all-reduce across GPUs that
+ * hold different chains of the same sources (chain-sharded layout).  dev buffers:
+ *  pass 0: sums_dev [P, S]    = sum_c mean_c
+ *  pass 1: given gmean_dev [P, S] (global mean of chain means), sums_dev [2, P, S] =
+ *          (sum_c (mean_c-gmean)^2, sum_c var_c)                                            */
+int mi355_rhat_partial_async(mi355_ctx* ctx, int32_t pass, const double* gmean_dev,
+                             double* sums_dev);
+/* Rhat = sqrt((W+B)/W), W = sum var / Ctot, B = sum (mean-gmean)^2 / (Ctot-1); NaN where W<=0
+ * (the reference drops those parameters, convergence.py:81-83).  rhat_dev [P, S]. */
+int mi355_rhat_finish_async(mi355_ctx* ctx, const double* sums_dev, int64_t Ctot, double* rhat_dev);
+/* Single-GPU convenience: all C chains are local.  rhat host [S, P]. */
+int mi355_rhat(mi355_ctx* ctx, double* rhat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355MCMC_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libmi355mcmc.so (include/mi355mcmc.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible when a
+context is created, the caller gets an exception - never a silently different code path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355mcmc.so")
+ABI_VERSION = 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class SedModel(C.Structure):
+    """mirror of mi355_sed_model"""
+    _fields_ = [("model", C.c_int32), ("nparam", C.c_int32), ("h_over_k", C.c_double),
+                ("nu_b", C.c_double), ("prefac", C.c_double), ("Tmin", C.c_double),
+                ("Tmax", C.c_double), ("bmin", C.c_double), ("bmax", C.c_double),
+                ("nu_rescale", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/mi355mcmc.h declares
+SIGNATURES = {
+    "mi355_init": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mi355_free": (None, [C.c_void_p]),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_abi_version": (C.c_int, []),
+    "mi355_stream": (C.c_void_p, [C.c_void_p]),
+    "mi355_sync": (C.c_int, [C.c_void_p]),
+    "mi355_sed_model_default": (C.c_int, [C.c_int32, C.POINTER(SedModel)]),
+    "mi355_sed_nparam": (C.c_int, [C.c_int32]),
+    "mi355_sed_load": (C.c_int, [C.c_void_p, C.POINTER(SedModel), C.c_int64, C.c_int32, c_int32_p,
+                                 c_double_p, c_double_p, c_double_p]),
+    "mi355_sed_lnlike": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p,
+                                   c_double_p, c_double_p]),
+    "mi355_sed_lnlike_dev_async": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "mi355_sed_prior_package": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "mi355_mh_init": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int32,
+                                c_int32_p, C.c_int32, C.c_int32]),
+    "mi355_mh_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_double_p, c_double_p]),
+    "mi355_mh_moments": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int64_p, c_int64_p,
+                                   c_double_p, c_double_p]),
+    "mi355_mh_stream_pos": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "mi355_mh_set_stream_pos": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    "mi355_mh_nsamples": (C.c_int64, [C.c_void_p]),
+    "mi355_mh_ntrace": (C.c_int64, [C.c_void_p]),
+    "mi355_mh_trace": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_uint8_p]),
+    "mi355_mh_adapt": (C.c_int, [C.c_void_p, C.c_double, C.c_int32]),
+    "mi355_rng_dump": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p,
+                                 c_double_p]),
+    "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mi355_rhat": (C.c_int, [C.c_void_p, c_double_p]),
+}
+
+_lib = None
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Mi355Error(
+            "libmi355mcmc.so not found at %s: build it with `make -C mcmc_amd/csrc` "
+            "(or __graft_entry__.build()); mcmc_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi355_abi_version() != ABI_VERSION:
+        raise Mi355Error("libmi355mcmc.so ABI %d != binding ABI %d" %
+                         (lib.mi355_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Mi355Error(load().mi355_last_error().decode("utf-8", "replace"))

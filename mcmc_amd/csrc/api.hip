@@ -1,0 +1,644 @@
+// C ABI of libmi355mcmc.so (declared in include/mi355mcmc.h): context, SED catalogue,
+// batched likelihood, Metropolis-Hastings state machine, Gelman-Rubin.
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "common.hpp"
+#include "sed_kernels.hpp"
+
+namespace mi355 {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+static const int kModelNParam[MI355_SED_NMODEL] = {3, 3, 6, 6, 2, 4, 4, 4};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr size_t kLdsLimit = 64 * 1024;   // dynamic LDS a block may ask for without opt-in
+
+// LDS bytes a `bs`-chain block needs for the band tables of the sources it can touch
+static size_t lds_bytes(int bs, int C, int nbm, int64_t nsources) {
+  int64_t per_block = (bs % C == 0) ? bs / C : (bs - 1) / C + 2;
+  if (per_block > nsources) per_block = nsources;
+  return static_cast<size_t>(per_block) * kBandFields * nbm * sizeof(double);
+}
+
+// Largest block (256/128/64 chains) whose band tables fit in LDS; 0 if none does.
+static int pick_block(int C, int nbm, int64_t nsources, size_t* lds) {
+  for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
+    *lds = lds_bytes(bs, C, nbm, nsources);
+    if (*lds <= kLdsLimit) return bs;
+  }
+  return 0;
+}
+
+template <template <int> class F, typename... A>
+static int dispatch_model(int model, A&&... args) {
+  switch (model) {
+    case MI355_SED_M1N: return F<MI355_SED_M1N>::run(std::forward<A>(args)...);
+    case MI355_SED_M1N_LOGA: return F<MI355_SED_M1N_LOGA>::run(std::forward<A>(args)...);
+    case MI355_SED_M2N: return F<MI355_SED_M2N>::run(std::forward<A>(args)...);
+    case MI355_SED_M2N_LOGA: return F<MI355_SED_M2N_LOGA>::run(std::forward<A>(args)...);
+    case MI355_SED_M1: return F<MI355_SED_M1>::run(std::forward<A>(args)...);
+    case MI355_SED_M2: return F<MI355_SED_M2>::run(std::forward<A>(args)...);
+    case MI355_SED_THICK: return F<MI355_SED_THICK>::run(std::forward<A>(args)...);
+    case MI355_SED_THICK_LOGA: return F<MI355_SED_THICK_LOGA>::run(std::forward<A>(args)...);
+  }
+  set_error("unknown SED model id %d", model);
+  return -1;
+}
+
+template <int M>
+struct LaunchLnlike {
+  static int run(mi355_ctx* c, int64_t s0, int64_t n_eval, int C, const double* theta, double* lnl,
+                 double* derived) {
+    size_t lds = 0;
+    const int bs = pick_block(C, c->nbm, ceil_div(n_eval, C), &lds);
+    MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, C);
+    const unsigned grid = static_cast<unsigned>(ceil_div(n_eval, bs));
+    hipLaunchKernelGGL(k_sed_lnlike<M>, dim3(grid), dim3(bs), lds, c->stream, c->bands.p,
+                       c->nb.p, c->nbm, s0, n_eval, C, theta, lnl, derived, c->kc);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
+};
+
+template <int M>
+struct LaunchPriorPackage {
+  static int run(mi355_ctx* c, int64_t n, const double* theta, double* prior, double* packaged) {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n, kBlockThreads));
+    hipLaunchKernelGGL(k_sed_prior_package<M>, dim3(grid), dim3(kBlockThreads), 0, c->stream, n,
+                       theta, prior, packaged, c->kc);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
+};
+
+template <int M>
+struct LaunchStart {
+  static int run(mi355_ctx* c, const MhArgs& a) {
+    size_t lds = 0;
+    const int bs = pick_block(c->C, c->nbm, c->S, &lds);
+    MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
+    const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
+    hipLaunchKernelGGL(k_mh_start<M>, dim3(grid), dim3(bs), lds, c->stream, a);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
+};
+
+template <int M>
+struct LaunchRun {
+  static int run(mi355_ctx* c, const MhArgs& a) {
+    size_t lds = 0;
+    const int bs = pick_block(c->C, c->nbm, c->S, &lds);
+    MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
+    const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
+    hipLaunchKernelGGL(k_mh_run<M>, dim3(grid), dim3(bs), lds, c->stream, a);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
+};
+
+static MhArgs base_args(mi355_ctx* c) {
+  MhArgs a{};
+  a.bands = c->bands.p;
+  a.nb = c->nb.p;
+  a.nbm = c->nbm;
+  a.C = c->C;
+  a.N = c->N;
+  a.theta = c->theta.p;
+  a.sigma = c->sigma.p;
+  a.lnPr = c->lnPr.p;
+  a.mean = c->mean.p;
+  a.m2 = c->m2.p;
+  a.naccept = c->naccept.p;
+  a.accept = c->accept.p;
+  a.flags = c->flags.p;
+  a.nblock = c->nblock;
+  for (int i = 0; i < kMaxParam; ++i) {
+    a.blockmask[i] = c->blockmask[i];
+    a.rank_in_block[i] = c->rank_in_block[i];
+  }
+  a.npn = c->npn;
+  a.step_total = c->step_total;
+  a.stage_step = c->stage_step;
+  a.nsamp0 = c->nsamp;
+  a.stage = c->stage;
+  a.seed = c->seed;
+  a.k = c->kc;
+  return a;
+}
+
+static int check_start_flags(mi355_ctx* c) {
+  std::vector<int32_t> f(static_cast<size_t>(c->N));
+  MI355_HIP(hipMemcpyAsync(f.data(), c->flags.p, f.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  int64_t bad = 0, first = -1;
+  for (int64_t i = 0; i < c->N; ++i)
+    if (f[i] & kFlagStartFailed) {
+      if (first < 0) first = i;
+      ++bad;
+    }
+  MI355_REQUIRE(bad == 0,
+                "ZeroPriorError: %lld of %lld chains could not be started with prior>0 "
+                "(first: chain %lld) [MCMC.py:174-175]",
+                static_cast<long long>(bad), static_cast<long long>(c->N),
+                static_cast<long long>(first));
+  return 0;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+const char* mi355_last_error(void) { return g_err.c_str(); }
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
+int mi355_init(int device, uint64_t seed, mi355_ctx** out) {
+  MI355_REQUIRE(out != nullptr, "mi355_init: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("mi355_init: no HIP device available (%s); this library has no CPU fallback",
+              hipGetErrorString(e));
+    return -2;
+  }
+  MI355_REQUIRE(device >= 0 && device < ndev, "mi355_init: device %d out of range [0,%d)", device,
+                ndev);
+  MI355_HIP(hipSetDevice(device));
+  mi355_ctx* c = new mi355_ctx();
+  c->device = device;
+  c->seed = seed;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete c;
+    return -2;
+  }
+  *out = c;
+  return 0;
+}
+
+void mi355_free(mi355_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+void* mi355_stream(mi355_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int mi355_sync(mi355_ctx* c) {
+  MI355_REQUIRE(c, "null context");
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_sed_nparam(int32_t model) {
+  if (model < 0 || model >= MI355_SED_NMODEL) return -1;
+  return kModelNParam[model];
+}
+
+int mi355_sed_model_default(int32_t model, mi355_sed_model* out) {
+  MI355_REQUIRE(out, "null output");
+  MI355_REQUIRE(model >= 0 && model < MI355_SED_NMODEL, "unknown SED model id %d", model);
+  out->model = model;
+  out->nparam = kModelNParam[model];
+  out->h_over_k = 0.04799237;
+  out->nu_b = 1000.0;
+  out->prefac = 1.0e-9;
+  out->Tmin = 3.0;
+  out->Tmax = 100.0;
+  out->bmin = 0.0;
+  out->bmax = 3.0;
+  out->nu_rescale = 1000.0;
+  return 0;
+}
+
+int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb_max,
+                   const int32_t* nb, const double* nu, const double* d, const double* sig) {
+  MI355_REQUIRE(c && m && nb && nu && d && sig, "mi355_sed_load: null argument");
+  MI355_REQUIRE(m->model >= 0 && m->model < MI355_SED_NMODEL, "unknown SED model id %d", m->model);
+  MI355_REQUIRE(m->nparam == kModelNParam[m->model], "model %d has %d parameters, got nparam=%d",
+                m->model, kModelNParam[m->model], m->nparam);
+  MI355_REQUIRE(S > 0 && nb_max > 0, "mi355_sed_load: empty catalogue (S=%lld, nb_max=%d)",
+                static_cast<long long>(S), nb_max);
+  MI355_REQUIRE(static_cast<size_t>(nb_max) * kBandFields * sizeof(double) <= kLdsLimit,
+                "nb_max=%d too large for the LDS band tables", nb_max);
+  for (int64_t s = 0; s < S; ++s)
+    MI355_REQUIRE(nb[s] >= 0 && nb[s] <= nb_max, "nb[%lld]=%d outside [0,%d]",
+                  static_cast<long long>(s), nb[s], nb_max);
+  MI355_HIP(hipSetDevice(c->device));
+  c->sed_loaded = false;
+  c->mh_ready = false;
+  c->model = *m;
+  c->P = m->nparam;
+  c->S = S;
+  c->nbm = nb_max;
+  c->kc = SedConsts{m->h_over_k, m->nu_b, m->prefac, m->Tmin, m->Tmax, m->bmin, m->bmax,
+                    m->nu_rescale, m->h_over_k * m->nu_b};
+  // host-side derived band fields (each rounded once, as the reference computes them)
+  const size_t stride = static_cast<size_t>(kBandFields) * nb_max;
+  std::vector<double> h(static_cast<size_t>(S) * stride);
+  for (int64_t s = 0; s < S; ++s) {
+    double* o = h.data() + s * stride;
+    for (int j = 0; j < nb_max; ++j) {
+      const bool live = j < nb[s];
+      const double v = live ? nu[s * nb_max + j] : m->nu_b;
+      const double sg = live ? sig[s * nb_max + j] : 1.0;
+      o[0 * nb_max + j] = v;
+      o[1 * nb_max + j] = m->h_over_k * v;       // x = h_over_k*nu/T     model.py:103
+      o[2 * nb_max + j] = v / m->nu_b;           // nu/nu_norm            model.py:109
+      o[3 * nb_max + j] = live ? d[s * nb_max + j] : 0.0;
+      o[4 * nb_max + j] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
+    }
+  }
+  if (c->bands.alloc(h.size())) return -2;
+  if (c->nb.alloc(static_cast<size_t>(S))) return -2;
+  MI355_HIP(hipMemcpyAsync(c->bands.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice,
+                           c->stream));
+  MI355_HIP(hipMemcpyAsync(c->nb.p, nb, static_cast<size_t>(S) * sizeof(int32_t),
+                           hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  c->sed_loaded = true;
+  return 0;
+}
+
+int mi355_sed_lnlike_dev_async(mi355_ctx* c, int64_t s0, int64_t ns, int32_t C,
+                               const double* theta_dev, double* lnL_dev, double* derived_dev) {
+  MI355_REQUIRE(c && c->sed_loaded, "mi355_sed_lnlike: no catalogue loaded (call mi355_sed_load)");
+  MI355_REQUIRE(theta_dev && lnL_dev, "mi355_sed_lnlike: null buffer");
+  MI355_REQUIRE(s0 >= 0 && ns > 0 && s0 + ns <= c->S, "source range [%lld,%lld) outside [0,%lld)",
+                static_cast<long long>(s0), static_cast<long long>(s0 + ns),
+                static_cast<long long>(c->S));
+  MI355_REQUIRE(C > 0, "C must be positive");
+  MI355_HIP(hipSetDevice(c->device));
+  return dispatch_model<LaunchLnlike>(c->model.model, c, s0, ns * C, static_cast<int>(C), theta_dev,
+                                      lnL_dev, derived_dev);
+}
+
+int mi355_sed_lnlike(mi355_ctx* c, int64_t s0, int64_t ns, int32_t C, const double* theta,
+                     double* lnL, double* derived) {
+  MI355_REQUIRE(c && c->sed_loaded, "mi355_sed_lnlike: no catalogue loaded (call mi355_sed_load)");
+  MI355_REQUIRE(theta && lnL, "mi355_sed_lnlike: null buffer");
+  MI355_REQUIRE(ns > 0 && C > 0, "empty batch");
+  MI355_HIP(hipSetDevice(c->device));
+  const int64_t n = ns * C;
+  const int P = c->P;
+  if (c->scratch_a.alloc(static_cast<size_t>(n) * P)) return -2;
+  if (c->scratch_b.alloc(static_cast<size_t>(n) * P)) return -2;
+  if (c->scratch_c.alloc(static_cast<size_t>(n) * 3)) return -2;
+  MI355_HIP(hipMemcpyAsync(c->scratch_a.p, theta, static_cast<size_t>(n) * P * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_transpose, dim3(static_cast<unsigned>(ceil_div(n * P, 256))), dim3(256), 0,
+                     c->stream, c->scratch_a.p, c->scratch_b.p, n, static_cast<int64_t>(P));
+  MI355_HIP(hipGetLastError());
+  double* lnl_d = c->scratch_c.p;
+  double* der_d = derived ? c->scratch_c.p + n : nullptr;
+  int rc = mi355_sed_lnlike_dev_async(c, s0, ns, C, c->scratch_b.p, lnl_d, der_d);
+  if (rc) return rc;
+  MI355_HIP(hipMemcpyAsync(lnL, lnl_d, static_cast<size_t>(n) * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> der_h;
+  if (derived) {
+    der_h.resize(static_cast<size_t>(n) * 2);
+    MI355_HIP(hipMemcpyAsync(der_h.data(), der_d, der_h.size() * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+  }
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  if (derived)
+    for (int64_t i = 0; i < n; ++i) {
+      derived[2 * i] = der_h[i];
+      derived[2 * i + 1] = der_h[n + i];
+    }
+  return 0;
+}
+
+int mi355_sed_prior_package(mi355_ctx* c, int64_t n, const double* theta, double* prior,
+                            double* packaged) {
+  MI355_REQUIRE(c && c->sed_loaded, "mi355_sed_prior_package: no model loaded");
+  MI355_REQUIRE(theta && n > 0, "empty batch");
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->P;
+  if (c->scratch_a.alloc(static_cast<size_t>(n) * P)) return -2;
+  if (c->scratch_b.alloc(static_cast<size_t>(n) * P)) return -2;
+  if (c->scratch_c.alloc(static_cast<size_t>(n))) return -2;
+  MI355_HIP(hipMemcpyAsync(c->scratch_a.p, theta, static_cast<size_t>(n) * P * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  int rc = dispatch_model<LaunchPriorPackage>(c->model.model, c, n, c->scratch_a.p,
+                                              prior ? c->scratch_c.p : nullptr,
+                                              packaged ? c->scratch_b.p : nullptr);
+  if (rc) return rc;
+  if (prior)
+    MI355_HIP(hipMemcpyAsync(prior, c->scratch_c.p, static_cast<size_t>(n) * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+  if (packaged)
+    MI355_HIP(hipMemcpyAsync(packaged, c->scratch_b.p, static_cast<size_t>(n) * P * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// upload a host [N][P] (per_chain) or [P] array as device [P][N] / [P]
+static int upload_param(mi355_ctx* c, const double* host, int per_chain, DevBuf<double>& tmp,
+                        DevBuf<double>& out) {
+  const int P = c->P;
+  if (!per_chain) {
+    if (out.alloc(static_cast<size_t>(P))) return -2;
+    MI355_HIP(hipMemcpyAsync(out.p, host, P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+  }
+  const size_t n = static_cast<size_t>(c->N) * P;
+  if (tmp.alloc(n) || out.alloc(n)) return -2;
+  MI355_HIP(hipMemcpyAsync(tmp.p, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_transpose, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
+                     c->stream, tmp.p, out.p, c->N, static_cast<int64_t>(P));
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+int mi355_mh_init(mi355_ctx* c, int32_t C, const double* theta0, int32_t theta0_per_chain,
+                  const double* sigma, int32_t sigma_per_chain, const int32_t* param_blocks,
+                  int32_t nblock, int32_t randomize_start) {
+  MI355_REQUIRE(c && c->sed_loaded, "mi355_mh_init: no catalogue loaded (call mi355_sed_load)");
+  MI355_REQUIRE(theta0 && sigma, "mi355_mh_init: null theta0/sigma");
+  MI355_REQUIRE(C > 0, "C must be positive");
+  MI355_REQUIRE(nblock >= 0 && nblock <= c->P, "nblock=%d outside [0,%d]", nblock, c->P);
+  MI355_REQUIRE(nblock == 0 || param_blocks, "param_blocks required when nblock>0");
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->P;
+  c->mh_ready = false;
+  c->C = C;
+  c->N = c->S * C;
+  c->nblock = nblock;
+  int maxblk = 1;
+  for (int b = 0; b < kMaxParam; ++b) c->blockmask[b] = 0;
+  for (int i = 0; i < kMaxParam; ++i) c->rank_in_block[i] = 0;
+  if (nblock > 0) {
+    int count[kMaxParam] = {0};
+    for (int i = 0; i < P; ++i) {
+      const int b = param_blocks[i];
+      MI355_REQUIRE(b >= -1 && b < nblock, "param_blocks[%d]=%d outside [-1,%d)", i, b, nblock);
+      if (b < 0) continue;   // parameter left out of every block (MCMC.py:85-88)
+      c->rank_in_block[i] = count[b]++;
+      c->blockmask[b] |= 1u << i;
+      if (count[b] > maxblk) maxblk = count[b];
+    }
+    c->npn = maxblk == 1 ? 1 : ((maxblk + 1) & ~1);
+  } else {
+    for (int i = 0; i < P; ++i) c->rank_in_block[i] = i;
+    c->npn = (P + 1) & ~1;
+  }
+  const size_t NP = static_cast<size_t>(c->N) * P;
+  if (c->theta.alloc(NP) || c->sigma.alloc(NP) || c->mean.alloc(NP) || c->m2.alloc(NP)) return -2;
+  if (c->lnPr.alloc(c->N) || c->naccept.alloc(c->N) || c->flags.alloc(c->N)) return -2;
+  if (c->accept.alloc(static_cast<size_t>(c->N) * (nblock > 0 ? nblock : 1))) return -2;
+  if (upload_param(c, theta0, theta0_per_chain, c->scratch_c, c->scratch_a)) return -2;
+  if (upload_param(c, sigma, sigma_per_chain, c->scratch_c, c->scratch_b)) return -2;
+  c->stage_step = 0;
+  c->nsamp = 0;
+  c->nkeep = 0;
+  MhArgs a = base_args(c);
+  a.center = c->scratch_a.p;
+  a.center_per_chain = theta0_per_chain;
+  a.sigma_in = c->scratch_b.p;
+  a.sigma_per_chain = sigma_per_chain;
+  a.randomize = randomize_start;
+  a.adapt = 0;
+  int rc = dispatch_model<LaunchStart>(c->model.model, c, a);
+  if (rc) return rc;
+  c->stage += 1;
+  rc = check_start_flags(c);
+  if (rc) return rc;
+  c->mh_ready = true;
+  return 0;
+}
+
+int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_normals,
+                 const double* inj_uniforms) {
+  MI355_REQUIRE(c && c->mh_ready, "mi355_mh_run: chains not initialised (call mi355_mh_init)");
+  MI355_REQUIRE(nsteps >= 0 && thin >= 0, "negative nsteps/thin");
+  MI355_REQUIRE((inj_normals == nullptr) == (inj_uniforms == nullptr),
+                "inj_normals and inj_uniforms must be given together");
+  if (nsteps == 0) return 0;
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->P;
+  MhArgs a = base_args(c);
+  a.nsteps = nsteps;
+  a.thin = thin;
+  if (inj_normals) {
+    const size_t nn = static_cast<size_t>(nsteps) * c->N * P, nu = static_cast<size_t>(nsteps) * c->N;
+    if (c->scratch_a.alloc(nn) || c->scratch_b.alloc(nu)) return -2;
+    MI355_HIP(hipMemcpyAsync(c->scratch_a.p, inj_normals, nn * sizeof(double), hipMemcpyHostToDevice,
+                             c->stream));
+    MI355_HIP(hipMemcpyAsync(c->scratch_b.p, inj_uniforms, nu * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+    a.inj_n = c->scratch_a.p;
+    a.inj_u = c->scratch_b.p;
+  }
+  c->nkeep = thin > 0 ? nsteps / thin : 0;
+  if (c->nkeep > 0) {
+    const size_t rows = static_cast<size_t>(c->nkeep) * c->N;
+    if (c->tr_theta.alloc(rows * P) || c->tr_lnPr.alloc(rows) || c->tr_acc.alloc(rows)) return -2;
+    a.tr_theta = c->tr_theta.p;
+    a.tr_lnPr = c->tr_lnPr.p;
+    a.tr_acc = c->tr_acc.p;
+  } else {
+    a.thin = 0;
+  }
+  int rc = dispatch_model<LaunchRun>(c->model.model, c, a);
+  if (rc) return rc;
+  c->step_total += nsteps;
+  c->stage_step += nsteps;
+  c->nsamp += nsteps;
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int64_t mi355_mh_stream_pos(mi355_ctx* c, int32_t which) {
+  if (!c) return -1;
+  return which == 0 ? c->step_total : c->stage;
+}
+
+int mi355_mh_set_stream_pos(mi355_ctx* c, int64_t step, int64_t stage) {
+  MI355_REQUIRE(c, "null context");
+  MI355_REQUIRE(step >= 0 && stage >= 0 && stage < (1 << 23), "stream position out of range");
+  c->step_total = step;
+  c->stage = stage;
+  return 0;
+}
+
+int64_t mi355_mh_nsamples(mi355_ctx* c) { return c ? c->nsamp : -1; }
+int64_t mi355_mh_ntrace(mi355_ctx* c) { return c ? c->nkeep : -1; }
+
+// device [P][N] -> host [N][P]
+static int download_param(mi355_ctx* c, const double* dev, double* host, double scale) {
+  const int P = c->P;
+  const size_t n = static_cast<size_t>(c->N) * P;
+  std::vector<double> tmp(n);
+  MI355_HIP(hipMemcpyAsync(tmp.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < P; ++i)
+    for (int64_t k = 0; k < c->N; ++k) host[k * P + i] = tmp[i * c->N + k] * scale;
+  return 0;
+}
+
+int mi355_mh_moments(mi355_ctx* c, double* mean, double* var, int64_t* naccept, int64_t* accept,
+                     double* lnPr, double* theta) {
+  MI355_REQUIRE(c && c->mh_ready, "mi355_mh_moments: chains not initialised");
+  MI355_HIP(hipSetDevice(c->device));
+  if (mean && download_param(c, c->mean.p, mean, 1.0)) return -2;
+  if (var) {
+    MI355_REQUIRE(c->nsamp > 0, "mi355_mh_moments: no samples accumulated yet");
+    if (download_param(c, c->m2.p, var, 1.0 / static_cast<double>(c->nsamp))) return -2;
+  }
+  if (theta && download_param(c, c->theta.p, theta, 1.0)) return -2;
+  if (lnPr) {
+    MI355_HIP(hipMemcpyAsync(lnPr, c->lnPr.p, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));
+  }
+  if (naccept) {
+    std::vector<uint32_t> t(static_cast<size_t>(c->N));
+    MI355_HIP(hipMemcpyAsync(t.data(), c->naccept.p, t.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t k = 0; k < c->N; ++k) naccept[k] = t[k];
+  }
+  if (accept && c->nblock > 0) {
+    std::vector<uint32_t> t(static_cast<size_t>(c->N) * c->nblock);
+    MI355_HIP(hipMemcpyAsync(t.data(), c->accept.p, t.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->nblock; ++b)
+      for (int64_t k = 0; k < c->N; ++k) accept[k * c->nblock + b] = t[b * c->N + k];
+  }
+  return 0;
+}
+
+int mi355_mh_trace(mi355_ctx* c, double* samples, double* lnPr, uint8_t* accepted) {
+  MI355_REQUIRE(c && c->mh_ready, "mi355_mh_trace: chains not initialised");
+  MI355_REQUIRE(c->nkeep > 0, "mi355_mh_trace: the last mi355_mh_run kept no trace (thin=0)");
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->P;
+  const size_t rows = static_cast<size_t>(c->nkeep) * c->N;
+  if (samples) {
+    std::vector<double> tmp(rows * P);
+    MI355_HIP(hipMemcpyAsync(tmp.data(), c->tr_theta.p, tmp.size() * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t r = 0; r < c->nkeep; ++r)
+      for (int i = 0; i < P; ++i)
+        for (int64_t k = 0; k < c->N; ++k)
+          samples[(r * c->N + k) * P + i] = tmp[(r * P + i) * c->N + k];
+  }
+  if (lnPr)
+    MI355_HIP(hipMemcpyAsync(lnPr, c->tr_lnPr.p, rows * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+  if (accepted)
+    MI355_HIP(hipMemcpyAsync(accepted, c->tr_acc.p, rows, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_mh_adapt(mi355_ctx* c, double fac, int32_t random_restart) {
+  MI355_REQUIRE(c && c->mh_ready, "mi355_mh_adapt: chains not initialised");
+  MI355_REQUIRE(c->nsamp > 0, "mi355_mh_adapt: no samples to adapt from");
+  MI355_HIP(hipSetDevice(c->device));
+  if (!(fac > 0.0)) fac = 2.4 / std::sqrt(static_cast<double>(c->P));   // MCMC.py:379-380
+  MhArgs a = base_args(c);
+  a.adapt = 1;
+  a.fac = fac;
+  a.random_restart = random_restart;
+  a.randomize = 1;
+  int rc = dispatch_model<LaunchStart>(c->model.model, c, a);
+  if (rc) return rc;
+  c->stage += 1;
+  c->stage_step = 0;
+  c->nsamp = 0;
+  c->nkeep = 0;
+  return check_start_flags(c);
+}
+
+int mi355_rng_dump(mi355_ctx* c, int64_t step0, int64_t nsteps, int64_t N, int32_t npn,
+                   double* normals, double* uniforms) {
+  MI355_REQUIRE(c && normals && uniforms, "mi355_rng_dump: null argument");
+  MI355_REQUIRE(nsteps > 0 && N > 0 && npn > 0, "empty request");
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t n = static_cast<size_t>(nsteps) * N;
+  if (c->scratch_a.alloc(n * npn) || c->scratch_b.alloc(n)) return -2;
+  hipLaunchKernelGGL(k_rng_dump, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
+                     c->stream, c->seed, step0, nsteps, N, npn, c->scratch_a.p, c->scratch_b.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(normals, c->scratch_a.p, n * npn * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+  MI355_HIP(hipMemcpyAsync(uniforms, c->scratch_b.p, n * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_rhat_partial_async(mi355_ctx* c, int32_t pass, const double* gmean_dev, double* sums_dev) {
+  MI355_REQUIRE(c && c->mh_ready, "mi355_rhat: chains not initialised");
+  MI355_REQUIRE(c->nsamp > 0, "mi355_rhat: no samples accumulated yet");
+  MI355_REQUIRE(sums_dev && (pass == 0 || gmean_dev), "mi355_rhat_partial: null buffer");
+  MI355_HIP(hipSetDevice(c->device));
+  const int64_t waves = c->S * c->P;
+  hipLaunchKernelGGL(k_rhat_partial, dim3(static_cast<unsigned>(ceil_div(waves * 64, kBlockThreads))),
+                     dim3(kBlockThreads), 0, c->stream, pass, c->P, c->S, c->C, c->N,
+                     1.0 / static_cast<double>(c->nsamp), c->mean.p, c->m2.p, gmean_dev, sums_dev);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+int mi355_rhat_finish_async(mi355_ctx* c, const double* sums_dev, int64_t Ctot, double* rhat_dev) {
+  MI355_REQUIRE(c && c->mh_ready && sums_dev && rhat_dev, "mi355_rhat_finish: bad argument");
+  MI355_REQUIRE(Ctot >= 2, "Gelman-Rubin needs at least 2 chains per source (got %lld)",
+                static_cast<long long>(Ctot));
+  MI355_HIP(hipSetDevice(c->device));
+  const int64_t n = c->S * c->P;
+  hipLaunchKernelGGL(k_rhat_finish, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
+                     c->stream, n, static_cast<double>(Ctot), sums_dev, rhat_dev);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+int mi355_rhat(mi355_ctx* c, double* rhat) {
+  MI355_REQUIRE(c && c->mh_ready && rhat, "mi355_rhat: bad argument");
+  const int64_t n = c->S * c->P;
+  if (c->scratch_a.alloc(static_cast<size_t>(n) * 4)) return -2;
+  double* gmean = c->scratch_a.p;
+  double* sums = c->scratch_a.p + n;
+  double* out = c->scratch_a.p + 3 * n;
+  int rc = mi355_rhat_partial_async(c, 0, nullptr, gmean);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scale, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, c->stream,
+                     n, 1.0 / static_cast<double>(c->C), gmean);
+  rc = mi355_rhat_partial_async(c, 1, gmean, sums);
+  if (rc) return rc;
+  rc = mi355_rhat_finish_async(c, sums, c->C, out);
+  if (rc) return rc;
+  std::vector<double> h(static_cast<size_t>(n));
+  MI355_HIP(hipMemcpyAsync(h.data(), out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  for (int p = 0; p < c->P; ++p)
+    for (int64_t s = 0; s < c->S; ++s) rhat[s * c->P + p] = h[p * c->S + s];
+  return 0;
+}
+
+}  // extern "C"

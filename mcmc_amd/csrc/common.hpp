@@ -1,0 +1,114 @@
+// Internal helpers shared by the HIP translation units of libmi355mcmc.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355mcmc.h"
+
+namespace mi355 {
+
+void set_error(const char* fmt, ...);
+
+#define MI355_HIP(call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      mi355::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                       __LINE__);                                                         \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+#define MI355_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      mi355::set_error(__VA_ARGS__);      \
+      return -1;                          \
+    }                                     \
+  } while (0)
+
+// Owning device buffer; freed with the context.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    release();
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      n = 0;
+      set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+      return -2;
+    }
+    n = count;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
+constexpr int kBandFields = 5;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2
+constexpr int kBlockThreads = 256;
+
+struct SedConsts {
+  double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
+  double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
+};
+
+}  // namespace mi355
+
+struct mi355_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t seed = 0;
+
+  // --- SED catalogue -----------------------------------------------------------------
+  bool sed_loaded = false;
+  mi355_sed_model model{};
+  mi355::SedConsts kc{};
+  int P = 0;
+  int64_t S = 0;
+  int nbm = 0;
+  mi355::DevBuf<double> bands;   // [S][kBandFields][nbm]
+  mi355::DevBuf<int32_t> nb;     // [S]
+
+  // --- chain state (N = S*C chains, parameter-major so lanes coalesce) --------------
+  bool mh_ready = false;
+  int C = 0;
+  int64_t N = 0;
+  int nblock = 0;                 // 0: doBlock=False
+  uint32_t blockmask[mi355::kMaxParam] = {0};
+  int32_t rank_in_block[mi355::kMaxParam] = {0};
+  int npn = 1;                    // normals drawn per step in free-running mode
+  int64_t step_total = 0;         // Philox stream position (never reset)
+  int64_t stage_step = 0;         // steps since the last init/adapt (iBlock = stage_step % nblock)
+  int64_t stage = 0;              // number of init/adapt calls (keys the start stream)
+  int64_t nsamp = 0;              // samples accumulated in the moments
+  mi355::DevBuf<double> theta, sigma, lnPr, mean, m2;
+  mi355::DevBuf<uint32_t> naccept, accept;
+  mi355::DevBuf<int32_t> flags;   // per-chain status bits (start randomisation failed ...)
+
+  // --- trace of the last run ----------------------------------------------------------
+  int64_t nkeep = 0;
+  mi355::DevBuf<double> tr_theta, tr_lnPr;
+  mi355::DevBuf<uint8_t> tr_acc;
+
+  // --- scratch ------------------------------------------------------------------------
+  mi355::DevBuf<double> scratch_a, scratch_b, scratch_c;
+};

@@ -1,0 +1,87 @@
+// Counter-based RNG for the proposal / accept draws: Philox4x32-10 (Salmon et al., SC11)
+// + Box-Muller.  Replaces numpy's global MT19937 (MCMC/Proposal.py:151, MCMC/MCMC.py:264).
+// Stream definition (restated bit-for-bit by oracle/refcpu.py philox_normal/philox_uniform):
+//   key  = (seed_lo ^ purpose*0x9E3779B9, seed_hi)
+//   ctr  = (pair_lo, pair_hi, chain_lo, chain_hi),  pair = idx >> 1
+//   words w0..w3 -> u1 = u53(w0,w1), u2 = u53(w2,w3),  u53(hi,lo) = ((hi<<21 | lo>>11)+0.5)*2^-53
+//   uniform(idx)  = idx even ? u1 : u2
+//   normal(idx)   = sqrt(-2 ln u1) * (idx even ? cos : sin)(2 pi u2)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mi355 {
+
+enum : uint32_t { RNG_NORMAL = 0, RNG_UNIFORM = 1, RNG_START = 2 };
+
+struct Philox4 {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = lo1;
+    c2 = n2;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+  const uint64_t k = (static_cast<uint64_t>(hi) << 21) | (static_cast<uint64_t>(lo) >> 11);
+  return (static_cast<double>(k) + 0.5) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ Philox4 philox_pair(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                               uint64_t pair) {
+  const uint32_t k0 = static_cast<uint32_t>(seed) ^ (purpose * 0x9E3779B9u);
+  const uint32_t k1 = static_cast<uint32_t>(seed >> 32);
+  return philox4x32_10(static_cast<uint32_t>(pair), static_cast<uint32_t>(pair >> 32),
+                       static_cast<uint32_t>(chain), static_cast<uint32_t>(chain >> 32), k0, k1);
+}
+
+// both uniforms of one pair
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                                uint64_t pair, double& ua, double& ub) {
+  const Philox4 r = philox_pair(seed, purpose, chain, pair);
+  ua = u53(r.w[0], r.w[1]);
+  ub = u53(r.w[2], r.w[3]);
+}
+
+// both normals of one pair (cos branch = even idx, sin branch = odd idx)
+__device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                               uint64_t pair, double& za, double& zb) {
+  double u1, u2;
+  philox_uniform2(seed, purpose, chain, pair, u1, u2);
+  const double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincos(2.0 * 3.141592653589793 * u2, &s, &c);
+  za = r * c;
+  zb = r * s;
+}
+
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                                uint64_t idx) {
+  double za, zb;
+  philox_normal2(seed, purpose, chain, idx >> 1, za, zb);
+  return (idx & 1) ? zb : za;
+}
+
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                                 uint64_t idx) {
+  double ua, ub;
+  philox_uniform2(seed, purpose, chain, idx >> 1, ua, ub);
+  return (idx & 1) ? ub : ua;
+}
+
+}  // namespace mi355

@@ -1,0 +1,188 @@
+// Device-side greybody models, Gaussian chi-square, priors and label canonicalisation.
+// One lane evaluates one (source, parameter vector); the band table of the lane's source is
+// read from LDS (broadcast reads when the lanes of a wave share a source).
+//
+// Reference arithmetic reproduced, evaluation order included (FP64 parity to 1e-12 depends on
+// it): MCMC/submmSED/model.py:80-111 (blackbody/greybody), :130-769 (model classes),
+// MCMC/GaussianData.py:31-64 (quadform/chi2), MCMC/submmSED/likelihood.py:35-155.
+#pragma once
+#include "common.hpp"
+
+namespace mi355 {
+
+// band table of one source in LDS: [kBandFields][nbm]
+struct Bands {
+  const double* base;
+  int nbm;
+  int nb;
+  __device__ __forceinline__ double nu(int j) const { return base[0 * nbm + j]; }
+  __device__ __forceinline__ double hnu(int j) const { return base[1 * nbm + j]; }    // h/k * nu
+  __device__ __forceinline__ double ratio(int j) const { return base[2 * nbm + j]; }  // nu / nu_b
+  __device__ __forceinline__ double d(int j) const { return base[3 * nbm + j]; }
+  __device__ __forceinline__ double w(int j) const { return base[4 * nbm + j]; }      // 1/sig^2
+};
+
+template <int MODEL>
+struct ModelTraits;
+template <> struct ModelTraits<MI355_SED_M1N> { static constexpr int P = 3; };
+template <> struct ModelTraits<MI355_SED_M1N_LOGA> { static constexpr int P = 3; };
+template <> struct ModelTraits<MI355_SED_M2N> { static constexpr int P = 6; };
+template <> struct ModelTraits<MI355_SED_M2N_LOGA> { static constexpr int P = 6; };
+template <> struct ModelTraits<MI355_SED_M1> { static constexpr int P = 2; };
+template <> struct ModelTraits<MI355_SED_M2> { static constexpr int P = 4; };
+template <> struct ModelTraits<MI355_SED_THICK> { static constexpr int P = 4; };
+template <> struct ModelTraits<MI355_SED_THICK_LOGA> { static constexpr int P = 4; };
+
+// ---- priors: model.py prior() classmethods -------------------------------------------------
+__device__ __forceinline__ bool t_ok(double T, const SedConsts& k, bool upper) {
+  return !(T < k.Tmin || (upper && T > k.Tmax));
+}
+__device__ __forceinline__ bool b_ok(double b, const SedConsts& k) {
+  return !(b < k.bmin || b > k.bmax);
+}
+
+template <int MODEL>
+__device__ __forceinline__ double sed_prior(const double* th, const SedConsts& k) {
+  if constexpr (MODEL == MI355_SED_M1N) {               // model.py:560-570
+    return (t_ok(th[2], k, true) && !(th[0] < 0) && b_ok(th[1], k)) ? 1.0 : 0.0;
+  } else if constexpr (MODEL == MI355_SED_M1N_LOGA) {   // model.py:759-769
+    return (t_ok(th[2], k, true) && b_ok(th[1], k)) ? 1.0 : 0.0;
+  } else if constexpr (MODEL == MI355_SED_M2N) {        // model.py:407-425
+    return (t_ok(th[2], k, true) && t_ok(th[5], k, true) && !(th[0] < 0) && !(th[3] < 0) &&
+            b_ok(th[1], k) && b_ok(th[4], k)) ? 1.0 : 0.0;
+  } else if constexpr (MODEL == MI355_SED_M2N_LOGA) {   // model.py:491-508
+    return (t_ok(th[2], k, true) && t_ok(th[5], k, true) && b_ok(th[1], k) && b_ok(th[4], k))
+               ? 1.0 : 0.0;
+  } else if constexpr (MODEL == MI355_SED_M1) {         // model.py:244-255
+    return (t_ok(th[1], k, false) && b_ok(th[0], k)) ? 1.0 : 0.0;
+  } else if constexpr (MODEL == MI355_SED_M2) {         // model.py:160-174
+    return (t_ok(th[1], k, false) && t_ok(th[3], k, false) && b_ok(th[0], k) && b_ok(th[2], k))
+               ? 1.0 : 0.0;
+  } else {                                              // model.py:674-693, :730-746
+    if (MODEL == MI355_SED_THICK && th[0] < 0) return 0.0;
+    if (!t_ok(th[2], k, true) || !b_ok(th[1], k) || th[3] < 0) return 0.0;
+    return exp(-3.0 * th[3]);
+  }
+}
+
+// ---- package(): T1<=T2 canonicalisation, model.py:192-196, :439-443, :510-514 --------------
+template <int MODEL>
+__device__ __forceinline__ void sed_package(double* th) {
+  if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+    if (th[2] > th[5]) {
+      double t;
+      t = th[0]; th[0] = th[3]; th[3] = t;
+      t = th[1]; th[1] = th[4]; th[4] = t;
+      t = th[2]; th[2] = th[5]; th[5] = t;
+    }
+  } else if constexpr (MODEL == MI355_SED_M2) {
+    if (th[1] > th[3]) {
+      double t;
+      t = th[0]; th[0] = th[2]; th[2] = t;
+      t = th[1]; th[1] = th[3]; th[3] = t;
+    }
+  }
+}
+
+// ---- likelihood --------------------------------------------------------------------------
+// Returns like.lnLike(theta) WITHOUT the prior.  derived[0..1] receive the ML amplitudes of
+// the marginalised likelihoods (NaN otherwise) when derived != nullptr.
+template <int MODEL>
+__device__ __forceinline__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& k,
+                                             double* derived) {
+  if (derived) { derived[0] = __builtin_nan(""); derived[1] = derived[0]; }
+
+  if constexpr (MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA ||
+                MODEL == MI355_SED_THICK_LOGA) {
+    // A * (nu/nu_b)^(3+beta) * expm1(x_b)/expm1(x)        model.py:107-109, :550-551
+    const double A = (MODEL == MI355_SED_M1N) ? th[0] : pow(10.0, th[0]);   // :755
+    const double beta = th[1], T = th[2];
+    const double en = expm1(k.hk_nub / T);
+    const double e3 = 3.0 + beta;
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double x = B.hnu(j) / T;
+      const double g = pow(B.ratio(j), e3) * en / expm1(x);
+      const double r = B.d(j) - A * g;
+      chi2 += (r * B.w(j)) * r;                            // GaussianData.py:47,64
+    }
+    return -0.5 * chi2;                                    // likelihood.py:155
+  } else if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+    const bool lg = (MODEL == MI355_SED_M2N_LOGA);         // model.py:394-396, :484-489
+    const double A1 = lg ? pow(10.0, th[0]) : th[0];
+    const double A2 = lg ? pow(10.0, th[3]) : th[3];
+    const double T1 = th[2], T2 = th[5];
+    const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
+    const double en1 = expm1(k.hk_nub / T1), en2 = expm1(k.hk_nub / T2);
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double hn = B.hnu(j), rt = B.ratio(j);
+      const double g1 = pow(rt, e1) * en1 / expm1(hn / T1);
+      const double g2 = pow(rt, e2) * en2 / expm1(hn / T2);
+      const double r = B.d(j) - (A1 * g1 + A2 * g2);
+      chi2 += (r * B.w(j)) * r;
+    }
+    return -0.5 * chi2;
+  } else if constexpr (MODEL == MI355_SED_M1) {
+    // prefac * nu_b^-beta * nu^(3+beta) / expm1(x)         model.py:111, :238-239
+    const double beta = th[0], T = th[1];
+    const double pre = k.prefac * pow(k.nu_b, -beta);
+    const double e3 = 3.0 + beta;
+    double FNiF = 0.0, FNid = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double g = pre * pow(B.nu(j), e3) / expm1(B.hnu(j) / T);
+      const double gw = g * B.w(j);
+      FNiF += gw * g;
+      FNid += gw * B.d(j);
+    }
+    const double amp = FNid / FNiF;                        // likelihood.py:101-110
+    if (derived) derived[0] = amp;
+    return 0.5 * FNid * amp;
+  } else if constexpr (MODEL == MI355_SED_M2) {
+    const double pre1 = k.prefac * pow(k.nu_b, -th[0]), pre2 = k.prefac * pow(k.nu_b, -th[2]);
+    const double e1 = 3.0 + th[0], e2 = 3.0 + th[2];
+    const double T1 = th[1], T2 = th[3];
+    double m00 = 0, m01 = 0, m11 = 0, b0 = 0, b1 = 0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double nu = B.nu(j), hn = B.hnu(j), w = B.w(j), d = B.d(j);
+      const double g1 = pre1 * pow(nu, e1) / expm1(hn / T1);
+      const double g2 = pre2 * pow(nu, e2) / expm1(hn / T2);
+      const double g1w = g1 * w, g2w = g2 * w;
+      m00 += g1w * g1; m01 += g1w * g2; m11 += g2w * g2;
+      b0 += g1w * d;   b1 += g2w * d;
+    }
+    // (F^T N^-1 F) z = F^T N^-1 d, 2x2 LU with partial pivoting       likelihood.py:49-74
+    double z0, z1;
+    if (fabs(m00) >= fabs(m01)) {
+      const double l = m01 / m00;
+      const double u11 = m11 - l * m01;
+      z1 = (b1 - l * b0) / u11;
+      z0 = (b0 - m01 * z1) / m00;
+      if (u11 == 0.0 || m00 == 0.0) z0 = z1 = __builtin_nan("");      // LinAlgError -> reject
+    } else {
+      const double l = m00 / m01;
+      const double u11 = m01 - l * m11;
+      z1 = (b0 - l * b1) / u11;
+      z0 = (b1 - m11 * z1) / m01;
+      if (u11 == 0.0) z0 = z1 = __builtin_nan("");
+    }
+    if (derived) { derived[0] = z0; derived[1] = z1; }
+    return 0.5 * (b0 * z0 + b1 * z1);
+  } else {  // MI355_SED_THICK                              model.py:641-657
+    const double A = th[0], b = th[1], T = th[2], nu0 = th[3];
+    const double en = expm1(k.hk_nub / T);
+    const double tau_b = pow(k.nu_b / nu0 / k.nu_rescale, b);
+    const double den = 1.0 - exp(-tau_b);
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double tau = pow(B.nu(j) / nu0 / k.nu_rescale, b);
+      const double bb = pow(B.ratio(j), 3.0) * en / expm1(B.hnu(j) / T);   // model.py:92
+      const double m = A * (1.0 - exp(-tau)) / den * bb;
+      const double r = B.d(j) - m;
+      chi2 += (r * B.w(j)) * r;
+    }
+    return -0.5 * chi2;
+  }
+}
+
+}  // namespace mi355

@@ -1,0 +1,413 @@
+// HIP kernels of the SED path: batched likelihood, chain start / adapt, fused MH steps.
+// Mapping: one lane = one (source, chain); a 256-thread block covers 256 consecutive chain
+// indices n = s*C + c, stages the band tables of the sources it touches in LDS once and keeps
+// every chain's state in registers for all the steps of a launch; HBM is touched only at launch
+// entry/exit (parameter-major arrays, so the 64 lanes of a wave read/write 512 contiguous bytes)
+// and for the optional trace.
+#pragma once
+#include "philox.hpp"
+#include "sed_device.hpp"
+
+namespace mi355 {
+
+struct MhArgs {
+  const double* bands;    // [S][kBandFields][nbm]
+  const int32_t* nb;      // [S]
+  int nbm;
+  int C;
+  int64_t N;
+  double* theta;          // [P][N]
+  double* sigma;          // [P][N]
+  double* lnPr;           // [N]
+  double* mean;           // [P][N]
+  double* m2;             // [P][N]
+  uint32_t* naccept;      // [N]
+  uint32_t* accept;       // [nblock][N]
+  int32_t* flags;         // [N]
+  int nblock;
+  uint32_t blockmask[kMaxParam];
+  int32_t rank_in_block[kMaxParam];
+  int npn;
+  int64_t nsteps;
+  int64_t step_total;
+  int64_t stage_step;
+  int64_t nsamp0;
+  int64_t stage;
+  uint64_t seed;
+  const double* inj_n;    // [nsteps][N][P] or null
+  const double* inj_u;    // [nsteps][N] or null
+  int thin;
+  double* tr_theta;       // [nkeep][P][N]
+  double* tr_lnPr;        // [nkeep][N]
+  uint8_t* tr_acc;        // [nkeep][N]
+  SedConsts k;
+  // start / adapt
+  const double* center;   // [P][N] or [P]
+  int center_per_chain;
+  const double* sigma_in; // [P][N] or [P]
+  int sigma_per_chain;
+  int randomize;
+  int adapt;              // 1: centre and sigma come from the chain's own moments
+  double fac;
+  int random_restart;
+};
+
+constexpr int kStartMaxTries = 100000;
+constexpr int kFlagStartFailed = 1;
+
+// Stage the band tables of sources [s_first, s_first+nsrc) into LDS (coalesced).
+__device__ __forceinline__ void stage_bands(double* smem, const double* bands, int64_t s_first,
+                                            int nsrc, int stride) {
+  const double* src = bands + s_first * stride;
+  const int total = nsrc * stride;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) smem[i] = src[i];
+  __syncthreads();
+}
+
+// ---- batched like.lnLike ------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
+    const double* __restrict__ bands, const int32_t* __restrict__ nb, int nbm, int64_t s0,
+    int64_t n_eval, int C, const double* __restrict__ theta, double* __restrict__ lnl,
+    double* __restrict__ derived, SedConsts k) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  extern __shared__ double smem[];
+  const int stride = kBandFields * nbm;
+  const int64_t e0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  const int64_t e_last = min(e0 + blockDim.x, n_eval) - 1;
+  const int64_t s_first = s0 + e0 / C;
+  const int nsrc = static_cast<int>(s0 + e_last / C - s_first) + 1;
+  stage_bands(smem, bands, s_first, nsrc, stride);
+  const int64_t e = e0 + threadIdx.x;
+  if (e >= n_eval) return;
+  const int64_t s = s0 + e / C;
+  double th[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) th[i] = theta[i * n_eval + e];
+  Bands B{smem + (s - s_first) * stride, nbm, nb[s]};
+  double der[2];
+  const double v = sed_lnlike<MODEL>(th, B, k, derived ? der : nullptr);
+  lnl[e] = v;
+  if (derived) {
+    derived[e] = der[0];
+    derived[n_eval + e] = der[1];
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads) void k_sed_prior_package(
+    int64_t n, const double* __restrict__ theta /*[n][P]*/, double* __restrict__ prior,
+    double* __restrict__ packaged /*[n][P]*/, SedConsts k) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double th[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) th[i] = theta[e * P + i];
+  if (prior) prior[e] = sed_prior<MODEL>(th, k);
+  if (packaged) {
+    sed_package<MODEL>(th);
+#pragma unroll
+    for (int i = 0; i < P; ++i) packaged[e * P + i] = th[i];
+  }
+}
+
+// ---- chain start (setStart, MCMC.py:138-187) and restart from moments (newMCMC, :343-413) ---
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  constexpr int PE = (P + 1) & ~1;   // normals per start draw, rounded up to whole Philox pairs
+  extern __shared__ double smem[];
+  const int stride = kBandFields * a.nbm;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
+  const int64_t s_first = n0 / a.C;
+  const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  stage_bands(smem, a.bands, s_first, nsrc, stride);
+  const int64_t n = n0 + threadIdx.x;
+  if (n >= a.N) return;
+  const int64_t s = n / a.C;
+  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s]};
+  const uint64_t sbase = static_cast<uint64_t>(a.stage) << 40;
+
+  double c[P], sg[P];
+  if (a.adapt) {
+    // newStart = package(mean), stdevs = package(stdev) - the reference canonicalises the
+    // stdev vector with the same T1>T2 swap rule (MCMC.py:299-307 -> model.package), kept.
+    double sd[P];
+    const double rn = 1.0 / static_cast<double>(a.nsamp0);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      c[i] = a.mean[i * a.N + n];
+      sd[i] = sqrt(a.m2[i * a.N + n] * rn);
+    }
+    sed_package<MODEL>(c);
+    sed_package<MODEL>(sd);
+    if (a.random_restart) {                               // MCMC.py:366
+#pragma unroll
+      for (int i = 0; i < P; i += 2) {
+        double za, zb;
+        philox_normal2(a.seed, RNG_START, n, (sbase + i) >> 1, za, zb);
+        c[i] += za * sd[i];
+        if (i + 1 < P) c[i + 1] += zb * sd[i + 1];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) sg[i] = a.fac * sd[i];    // MCMC.py:385
+    sed_package<MODEL>(sg);
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      c[i] = a.center_per_chain ? a.center[i * a.N + n] : a.center[i];
+      sg[i] = a.sigma_per_chain ? a.sigma_in[i * a.N + n] : a.sigma_in[i];
+    }
+  }
+
+  double th[P];
+  double prior;
+  int flag = 0;
+  if (a.randomize) {                                      // MCMC.py:151-159
+    prior = -1.0;
+    int tries = 0;
+    while (!(prior > 0.0)) {
+      ++tries;
+      if (tries > kStartMaxTries) { flag = kFlagStartFailed; break; }
+      const uint64_t base = sbase + static_cast<uint64_t>(tries) * PE;
+#pragma unroll
+      for (int i = 0; i < P; i += 2) {
+        double za, zb;
+        philox_normal2(a.seed, RNG_START, n, (base + i) >> 1, za, zb);
+        th[i] = c[i] + za * sg[i];
+        if (i + 1 < P) th[i + 1] = c[i + 1] + zb * sg[i + 1];
+      }
+      sed_package<MODEL>(th);
+      prior = sed_prior<MODEL>(th, a.k);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; ++i) th[i] = c[i];
+    sed_package<MODEL>(th);
+    prior = sed_prior<MODEL>(th, a.k);
+    if (!(prior > 0.0)) flag = kFlagStartFailed;          // ZeroPriorError, MCMC.py:174-175
+  }
+  double lp = __builtin_nan("");
+  if (!flag) {
+    lp = sed_lnlike<MODEL>(th, B, a.k, nullptr);
+    if (prior != 1.0) lp += log(prior);                   // MCMC.py:177
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    a.theta[i * a.N + n] = th[i];
+    a.sigma[i * a.N + n] = sg[i];
+    a.mean[i * a.N + n] = 0.0;
+    a.m2[i * a.N + n] = 0.0;
+  }
+  a.lnPr[n] = lp;
+  a.naccept[n] = 1;                                       // MCMC.py:179
+  for (int b = 0; b < a.nblock; ++b) a.accept[b * a.N + n] = 1;   // :181
+  a.flags[n] = flag;
+}
+
+// ---- fused propose / evaluate / accept, nsteps per launch (MCMC.py:225-286) ------------------
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads) void k_mh_run(MhArgs a) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  extern __shared__ double smem[];
+  const int stride = kBandFields * a.nbm;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
+  const int64_t s_first = n0 / a.C;
+  const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  stage_bands(smem, a.bands, s_first, nsrc, stride);
+  const int64_t n = n0 + threadIdx.x;
+  if (n >= a.N) return;
+  const int64_t s = n / a.C;
+  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s]};
+
+  double th[P], sg[P], mu[P], m2[P];
+  uint32_t accb[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    th[i] = a.theta[i * a.N + n];
+    sg[i] = a.sigma[i * a.N + n];
+    mu[i] = a.mean[i * a.N + n];
+    m2[i] = a.m2[i * a.N + n];
+    accb[i] = (i < a.nblock) ? a.accept[i * a.N + n] : 0u;
+  }
+  double lnPr = a.lnPr[n];
+  uint32_t nacc = a.naccept[n];
+
+  const bool inject = a.inj_n != nullptr;
+  const uint32_t allmask = (1u << P) - 1u;
+  int blk = a.nblock ? static_cast<int>(a.stage_step % a.nblock) : 0;
+  int thin_ctr = 0;
+  int64_t row = 0;
+  double za = 0.0, zb = 0.0, ua = 0.0, ub = 0.0;   // cached Philox pairs (npn == 1)
+
+  for (int64_t t = 0; t < a.nsteps; ++t) {
+    const uint32_t mask = a.nblock ? a.blockmask[blk] : allmask;
+    const uint64_t step = static_cast<uint64_t>(a.step_total + t);
+    double nw[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) nw[i] = th[i];
+    double u;
+    if (inject) {
+      const double* zn = a.inj_n + (t * a.N + n) * P;
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        if ((mask >> i) & 1u) nw[i] += zn[i] * sg[i];      // Proposal.py:151,156-159
+      u = a.inj_u[t * a.N + n];
+    } else {
+      if (a.npn == 1) {
+        if (t == 0 || (step & 1u) == 0) {
+          philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+          philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
+        }
+        const double z = (step & 1u) ? zb : za;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          if ((mask >> i) & 1u) nw[i] += z * sg[i];
+        u = (step & 1u) ? ub : ua;
+      } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          if ((mask >> i) & 1u)
+            nw[i] += philox_normal(a.seed, RNG_NORMAL, n, step * a.npn + a.rank_in_block[i]) * sg[i];
+        u = philox_uniform(a.seed, RNG_UNIFORM, n, step);
+      }
+    }
+    sed_package<MODEL>(nw);                                // Proposal.py:164
+    // The reference evaluates the likelihood before the prior (MCMC.py:236-245); the outcome
+    // (reject, keep prev) is the same with the prior tested first, which skips the evaluation.
+    const double prior = sed_prior<MODEL>(nw, a.k);
+    bool accepted = false;
+    double next = lnPr;
+    if (prior > 0.0) {
+      double v = sed_lnlike<MODEL>(nw, B, a.k, nullptr);
+      const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
+      if (!bad) {
+        if (prior != 1.0) v += log(prior);                 // :250
+        const double lnalpha = v - lnPr;                   // :251 (+ lndensityRatio = 0, :252)
+        const bool reject = !(lnalpha >= 0.0) && !(exp(lnalpha) > u);   // :264
+        if (!reject) {
+          accepted = true;
+          next = v;
+        }
+      }
+    }
+    if (accepted) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) th[i] = nw[i];
+      lnPr = next;
+      ++nacc;                                              // :269
+#pragma unroll
+      for (int b = 0; b < P; ++b) accb[b] += (b == blk && a.nblock) ? 1u : 0u;   // :271
+    }
+    if (a.nblock) blk = (blk + 1 == a.nblock) ? 0 : blk + 1;   // :278-279
+
+    // running ddof=0 moments over every appended sample (mean/stdev with burn=1, :290-307)
+    const double rn = 1.0 / static_cast<double>(a.nsamp0 + t + 1);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const double dlt = th[i] - mu[i];
+      mu[i] += dlt * rn;
+      m2[i] += dlt * (th[i] - mu[i]);
+    }
+    if (a.thin > 0) {
+      if (++thin_ctr == a.thin) {
+        thin_ctr = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) a.tr_theta[(row * P + i) * a.N + n] = th[i];
+        a.tr_lnPr[row * a.N + n] = lnPr;
+        a.tr_acc[row * a.N + n] = accepted ? 1 : 0;
+        ++row;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    a.theta[i * a.N + n] = th[i];
+    a.mean[i * a.N + n] = mu[i];
+    a.m2[i * a.N + n] = m2[i];
+    if (i < a.nblock) a.accept[i * a.N + n] = accb[i];
+  }
+  a.lnPr[n] = lnPr;
+  a.naccept[n] = nacc;
+}
+
+// ---- RNG diagnostic -----------------------------------------------------------------------
+__global__ void k_rng_dump(uint64_t seed, int64_t step0, int64_t nsteps, int64_t N, int npn,
+                           double* normals, double* uniforms) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= nsteps * N) return;
+  const int64_t t = i / N, n = i % N;
+  const uint64_t step = static_cast<uint64_t>(step0 + t);
+  for (int r = 0; r < npn; ++r)
+    normals[i * npn + r] = philox_normal(seed, RNG_NORMAL, n, step * npn + r);
+  uniforms[i] = philox_uniform(seed, RNG_UNIFORM, n, step);
+}
+
+// ---- layout helpers -----------------------------------------------------------------------
+// in [rows][cols] -> out [cols][rows]
+__global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int64_t rows,
+                            int64_t cols) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols, c = i % cols;
+  out[c * rows + r] = in[i];
+}
+
+// ---- Gelman-Rubin partial sums (convergence.py:71-85) ---------------------------------------
+// one wave per (source, parameter): lanes stride over the source's C chains
+__global__ __launch_bounds__(kBlockThreads) void k_rhat_partial(
+    int pass, int P, int64_t S, int C, int64_t N, double rn, const double* __restrict__ mean,
+    const double* __restrict__ m2, const double* __restrict__ gmean, double* __restrict__ sums) {
+  const int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= S * P) return;
+  const int64_t s = w / P;
+  const int p = static_cast<int>(w % P);
+  const double* mp = mean + p * N + s * C;
+  const double* vp = m2 + p * N + s * C;
+  double a0 = 0.0, a1 = 0.0;
+  if (pass == 0) {
+    for (int c = lane; c < C; c += 64) a0 += mp[c];
+  } else {
+    const double g = gmean[p * S + s];
+    for (int c = lane; c < C; c += 64) {
+      const double dm = mp[c] - g;
+      a0 += dm * dm;
+      a1 += vp[c] * rn;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off);
+    a1 += __shfl_xor(a1, off);
+  }
+  if (lane == 0) {
+    if (pass == 0) {
+      sums[p * S + s] = a0;
+    } else {
+      sums[p * S + s] = a0;
+      sums[P * S + p * S + s] = a1;
+    }
+  }
+}
+
+__global__ void k_rhat_finish(int64_t n, double Ctot, const double* __restrict__ sums,
+                              double* __restrict__ rhat) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double within = sums[n + i] / Ctot;              // mean of the chain variances, :77
+  const double between = sums[i] / (Ctot - 1.0);         // ddof=1 variance of the means, :78
+  rhat[i] = (within > 0.0) ? sqrt((within + between) / within) : __builtin_nan("");   // :81-85
+}
+
+__global__ void k_scale(int64_t n, double f, double* x) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= f;
+}
+
+}  // namespace mi355

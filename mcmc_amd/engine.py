@@ -1,0 +1,215 @@
+"""Thin numpy-facing wrapper of the C ABI: one Engine = one mi355_ctx = one GPU + one stream.
+
+The reference-shaped classes (mcmc_amd.MCMC, .Likelihood, .submmSED ...) sit on top of this."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Mi355Error, SedModel, c_double_p, c_int32_p, c_int64_p, c_uint8_p, check
+
+MODEL_IDS = {"M1N": 0, "M1N_LOGA": 1, "M2N": 2, "M2N_LOGA": 3, "M1": 4, "M2": 5, "THICK": 6,
+             "THICK_LOGA": 7}
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("expected array of shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+class Engine:
+    def __init__(self, device=0, seed=0x5EDC0FFEE):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.mi355_init(int(device), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.seed = int(seed)
+        self.P = self.S = self.C = self.nblock = 0
+        self.nb_max = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mi355_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def N(self):
+        return self.S * self.C
+
+    @property
+    def stream(self):
+        return self.lib.mi355_stream(self._h)
+
+    def sync(self):
+        check(self.lib.mi355_sync(self._h))
+
+    # ---- SED catalogue -----------------------------------------------------------------
+    def default_model(self, model):
+        m = SedModel()
+        check(self.lib.mi355_sed_model_default(int(MODEL_IDS.get(model, model)), C.byref(m)))
+        return m
+
+    def sed_load(self, model, nb, nu, d, sig, consts=None):
+        """nb [S] int32; nu, d, sig [S, nb_max]."""
+        m = consts if isinstance(consts, SedModel) else self.default_model(model)
+        if isinstance(consts, dict):
+            for k, v in consts.items():
+                setattr(m, k, v)
+        nu = _f64(nu)
+        if nu.ndim != 2:
+            raise ValueError("nu must be [S, nb_max]")
+        S, nbm = nu.shape
+        d = _f64(d, (S, nbm))
+        sig = _f64(sig, (S, nbm))
+        nb = np.ascontiguousarray(nb, dtype=np.int32)
+        if nb.shape != (S,):
+            raise ValueError("nb must be [S]")
+        check(self.lib.mi355_sed_load(self._h, C.byref(m), S, nbm, nb.ctypes.data_as(c_int32_p),
+                                      _dp(nu), _dp(d), _dp(sig)))
+        self.model = m
+        self.P, self.S, self.nb_max = int(m.nparam), int(S), int(nbm)
+        self.C = 0
+
+    def sed_lnlike(self, theta, s0=0, derived=False):
+        """theta [ns, C, P] -> lnL [ns, C] (and derived [ns, C, 2])."""
+        theta = _f64(theta)
+        if theta.ndim != 3 or theta.shape[2] != self.P:
+            raise ValueError("theta must be [ns, C, %d]" % self.P)
+        ns, Cc, _ = theta.shape
+        out = np.empty((ns, Cc))
+        der = np.empty((ns, Cc, 2)) if derived else None
+        check(self.lib.mi355_sed_lnlike(self._h, int(s0), ns, Cc, _dp(theta), _dp(out), _dp(der)))
+        return (out, der) if derived else out
+
+    def sed_lnlike_dev(self, theta_ptr, lnl_ptr, ns, Cc, s0=0, derived_ptr=None):
+        check(self.lib.mi355_sed_lnlike_dev_async(self._h, int(s0), int(ns), int(Cc),
+                                                  C.c_void_p(theta_ptr), C.c_void_p(lnl_ptr),
+                                                  C.c_void_p(derived_ptr) if derived_ptr else None))
+
+    def sed_prior_package(self, theta):
+        theta = _f64(theta)
+        flat = theta.reshape(-1, self.P)
+        pr = np.empty(flat.shape[0])
+        pk = np.empty_like(flat)
+        check(self.lib.mi355_sed_prior_package(self._h, flat.shape[0], _dp(flat), _dp(pr), _dp(pk)))
+        return pr.reshape(theta.shape[:-1]), pk.reshape(theta.shape)
+
+    # ---- Metropolis-Hastings -------------------------------------------------------------
+    def mh_init(self, C_chains, theta0, sigma, param_blocks=None, randomize_start=True):
+        theta0 = _f64(theta0)
+        sigma = _f64(sigma)
+        Cc = int(C_chains)
+        per_t = int(theta0.ndim > 1)
+        per_s = int(sigma.ndim > 1)
+        if per_t:
+            theta0 = _f64(theta0.reshape(self.S, Cc, self.P))
+        elif theta0.shape != (self.P,):
+            raise ValueError("theta0 must be [P] or [S,C,P]")
+        if per_s:
+            sigma = _f64(sigma.reshape(self.S, Cc, self.P))
+        elif sigma.shape != (self.P,):
+            raise ValueError("sigma must be [P] or [S,C,P]")
+        if param_blocks is None:
+            pb, nblock = None, 0
+        else:
+            pb = np.ascontiguousarray(param_blocks, dtype=np.int32)
+            if pb.shape != (self.P,):
+                raise ValueError("param_blocks must be [P]")
+            nblock = int(pb.max()) + 1
+        check(self.lib.mi355_mh_init(self._h, Cc, _dp(theta0), per_t, _dp(sigma), per_s,
+                                     pb.ctypes.data_as(c_int32_p) if pb is not None else None,
+                                     nblock, int(bool(randomize_start))))
+        self.C, self.nblock = Cc, nblock
+
+    def mh_run(self, nsteps, thin=0, inj_normals=None, inj_uniforms=None):
+        if inj_normals is not None:
+            inj_normals = _f64(inj_normals, (nsteps, self.N, self.P))
+            inj_uniforms = _f64(inj_uniforms, (nsteps, self.N))
+        check(self.lib.mi355_mh_run(self._h, int(nsteps), int(thin), _dp(inj_normals),
+                                    _dp(inj_uniforms)))
+
+    def mh_moments(self):
+        S, Cc, P = self.S, self.C, self.P
+        out = dict(theta=np.empty((S, Cc, P)), lnPr=np.empty((S, Cc)),
+                   naccept=np.empty((S, Cc), np.int64),
+                   accept=np.empty((S, Cc, max(self.nblock, 0)), np.int64))
+        have = self.nsamples > 0
+        if have:
+            out["mean"] = np.empty((S, Cc, P))
+            out["var"] = np.empty((S, Cc, P))
+        check(self.lib.mi355_mh_moments(
+            self._h, _dp(out.get("mean")), _dp(out.get("var")),
+            out["naccept"].ctypes.data_as(c_int64_p),
+            out["accept"].ctypes.data_as(c_int64_p) if self.nblock else None,
+            _dp(out["lnPr"]), _dp(out["theta"])))
+        return out
+
+    @property
+    def nsamples(self):
+        return int(self.lib.mi355_mh_nsamples(self._h))
+
+    @property
+    def step_total(self):
+        return int(self.lib.mi355_mh_stream_pos(self._h, 0))
+
+    @property
+    def stage(self):
+        return int(self.lib.mi355_mh_stream_pos(self._h, 1))
+
+    def set_stream_pos(self, step, stage):
+        check(self.lib.mi355_mh_set_stream_pos(self._h, int(step), int(stage)))
+
+    def mh_trace(self):
+        nk = int(self.lib.mi355_mh_ntrace(self._h))
+        S, Cc, P = self.S, self.C, self.P
+        samples = np.empty((nk, S, Cc, P))
+        lnPr = np.empty((nk, S, Cc))
+        acc = np.empty((nk, S, Cc), np.uint8)
+        check(self.lib.mi355_mh_trace(self._h, _dp(samples), _dp(lnPr), acc.ctypes.data_as(c_uint8_p)))
+        return samples, lnPr, acc.astype(bool)
+
+    def mh_adapt(self, fac=None, random_restart=False):
+        check(self.lib.mi355_mh_adapt(self._h, float(fac) if fac else 0.0, int(bool(random_restart))))
+
+    def rng_dump(self, step0, nsteps, N, npn):
+        z = np.empty((nsteps, N, npn))
+        u = np.empty((nsteps, N))
+        check(self.lib.mi355_rng_dump(self._h, int(step0), int(nsteps), int(N), int(npn), _dp(z), _dp(u)))
+        return z, u
+
+    # ---- Gelman-Rubin ----------------------------------------------------------------------
+    def rhat(self):
+        out = np.empty((self.S, self.P))
+        check(self.lib.mi355_rhat(self._h, _dp(out)))
+        return out
+
+    def rhat_partial(self, pass_, sums_ptr, gmean_ptr=None):
+        check(self.lib.mi355_rhat_partial_async(self._h, int(pass_),
+                                                C.c_void_p(gmean_ptr) if gmean_ptr else None,
+                                                C.c_void_p(sums_ptr)))
+
+    def rhat_finish(self, sums_ptr, Ctot, rhat_ptr):
+        check(self.lib.mi355_rhat_finish_async(self._h, C.c_void_p(sums_ptr), int(Ctot),
+                                               C.c_void_p(rhat_ptr)))
+
+
+__all__ = ["Engine", "Mi355Error", "MODEL_IDS"]
