@@ -36,6 +36,10 @@ int mi355_init(int device, uint64_t seed, mi355_ctx** out);
 void mi355_free(mi355_ctx* ctx);
 const char* mi355_last_error(void);
 int mi355_abi_version(void);
+/* Duration in ms of the main kernel of the last mi355_mh_run / mi355_sed_lnlike* call, measured
+ * with HIP events recorded on the context stream around that launch (waits for it to finish).
+ * Returns <0 if no such kernel has been launched. */
+double mi355_last_kernel_ms(mi355_ctx* ctx);
 /* the HIP stream (hipStream_t) all kernels of this context are launched on */
 void* mi355_stream(mi355_ctx* ctx);
 int mi355_sync(mi355_ctx* ctx);

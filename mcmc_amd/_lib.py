@@ -30,6 +30,7 @@ SIGNATURES = {
     "mi355_free": (None, [C.c_void_p]),
     "mi355_last_error": (C.c_char_p, []),
     "mi355_abi_version": (C.c_int, []),
+    "mi355_last_kernel_ms": (C.c_double, [C.c_void_p]),
     "mi355_stream": (C.c_void_p, [C.c_void_p]),
     "mi355_sync": (C.c_int, [C.c_void_p]),
     "mi355_sed_model_default": (C.c_int, [C.c_int32, C.POINTER(SedModel)]),

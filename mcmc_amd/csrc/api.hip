@@ -66,9 +66,12 @@ struct LaunchLnlike {
     const int bs = pick_block(C, c->nbm, ceil_div(n_eval, C), &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, C);
     const unsigned grid = static_cast<unsigned>(ceil_div(n_eval, bs));
+    MI355_HIP(hipEventRecord(c->ev0, c->stream));
     hipLaunchKernelGGL(k_sed_lnlike<M>, dim3(grid), dim3(bs), lds, c->stream, c->bands.p,
                        c->nb.p, c->nbm, s0, n_eval, C, theta, lnl, derived, c->kc);
     MI355_HIP(hipGetLastError());
+    MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
     return 0;
   }
 };
@@ -104,8 +107,11 @@ struct LaunchRun {
     const int bs = pick_block(c->C, c->nbm, c->S, &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
+    MI355_HIP(hipEventRecord(c->ev0, c->stream));
     hipLaunchKernelGGL(k_mh_run<M>, dim3(grid), dim3(bs), lds, c->stream, a);
     MI355_HIP(hipGetLastError());
+    MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
     return 0;
   }
 };
@@ -185,9 +191,11 @@ int mi355_init(int device, uint64_t seed, mi355_ctx** out) {
   c->device = device;
   c->seed = seed;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e != hipSuccess) {
-    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
-    delete c;
+    set_error("stream/event creation failed: %s", hipGetErrorString(e));
+    mi355_free(c);
     return -2;
   }
   *out = c;
@@ -201,7 +209,17 @@ void mi355_free(mi355_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
+}
+
+double mi355_last_kernel_ms(mi355_ctx* c) {
+  if (!c || !c->ev_valid) return -1.0;
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+  return static_cast<double>(ms);
 }
 
 void* mi355_stream(mi355_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
@@ -253,8 +271,15 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
   c->P = m->nparam;
   c->S = S;
   c->nbm = nb_max;
+  auto dd_log = [](double v, double* hi, double* lo) {   // ln(v) as hi + lo (x87 80-bit logl)
+    const long double l = logl(static_cast<long double>(v));
+    *hi = static_cast<double>(l);
+    *lo = static_cast<double>(l - static_cast<long double>(*hi));
+  };
   c->kc = SedConsts{m->h_over_k, m->nu_b, m->prefac, m->Tmin, m->Tmax, m->bmin, m->bmax,
-                    m->nu_rescale, m->h_over_k * m->nu_b};
+                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0};
+  dd_log(m->nu_b, &c->kc.ln_nub_hi, &c->kc.ln_nub_lo);
+  const bool base_is_nu = (m->model == MI355_SED_M1 || m->model == MI355_SED_M2);
   // host-side derived band fields (each rounded once, as the reference computes them)
   const size_t stride = static_cast<size_t>(kBandFields) * nb_max;
   std::vector<double> h(static_cast<size_t>(S) * stride);
@@ -269,6 +294,12 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
       o[2 * nb_max + j] = v / m->nu_b;           // nu/nu_norm            model.py:109
       o[3 * nb_max + j] = live ? d[s * nb_max + j] : 0.0;
       o[4 * nb_max + j] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
+      // ln of the band's power-law base (the rounded double the reference raises to 3+beta)
+      dd_log(base_is_nu ? v : v / m->nu_b, &o[5 * nb_max + j], &o[6 * nb_max + j]);
+      if (live)
+        MI355_REQUIRE(v > 0.0 && std::isfinite(v) && std::fabs(o[5 * nb_max + j]) < 100.0,
+                      "source %lld band %d: frequency %g GHz out of range",
+                      static_cast<long long>(s), j, v);
     }
   }
   if (c->bands.alloc(h.size())) return -2;

@@ -63,12 +63,13 @@ struct DevBuf {
 };
 
 constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
-constexpr int kBandFields = 5;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2
+constexpr int kBandFields = 7;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, ln(base) hi, lo
 constexpr int kBlockThreads = 256;
 
 struct SedConsts {
   double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
+  double ln_nub_hi, ln_nub_lo;   // ln(nu_b) as a double-double
 };
 
 }  // namespace mi355
@@ -76,6 +77,8 @@ struct SedConsts {
 struct mi355_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the main kernel of the last call
+  bool ev_valid = false;
   uint64_t seed = 0;
 
   // --- SED catalogue -----------------------------------------------------------------

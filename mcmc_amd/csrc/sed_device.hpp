@@ -7,6 +7,7 @@
 // MCMC/GaussianData.py:31-64 (quadform/chi2), MCMC/submmSED/likelihood.py:35-155.
 #pragma once
 #include "common.hpp"
+#include "fastmath.hpp"
 
 namespace mi355 {
 
@@ -20,6 +21,10 @@ struct Bands {
   __device__ __forceinline__ double ratio(int j) const { return base[2 * nbm + j]; }  // nu / nu_b
   __device__ __forceinline__ double d(int j) const { return base[3 * nbm + j]; }
   __device__ __forceinline__ double w(int j) const { return base[4 * nbm + j]; }      // 1/sig^2
+  // ln(base) = lhi + llo of the band's power-law base: nu/nu_b for the normalised models,
+  // nu for submmModel1/2 (set per catalogue by mi355_sed_load)
+  __device__ __forceinline__ double lhi(int j) const { return base[5 * nbm + j]; }
+  __device__ __forceinline__ double llo(int j) const { return base[6 * nbm + j]; }
 };
 
 template <int MODEL>
@@ -84,12 +89,88 @@ __device__ __forceinline__ void sed_package(double* th) {
   }
 }
 
-// ---- likelihood --------------------------------------------------------------------------
-// Returns like.lnLike(theta) WITHOUT the prior.  derived[0..1] receive the ML amplitudes of
-// the marginalised likelihoods (NaN otherwise) when derived != nullptr.
 template <int MODEL>
-__device__ __forceinline__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& k,
-                                             double* derived) {
+__device__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& k, double* derived);
+
+// All parameters finite (NaN/inf proposals can only be rejected: MCMC.py:238-243).
+template <int P>
+__device__ __forceinline__ bool all_finite(const double* th) {
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) s += fabs(th[i]);
+  return s < __builtin_inf();
+}
+
+// ---- likelihood, fast path -------------------------------------------------------------------
+// like.lnLike(theta) WITHOUT the prior, for theta INSIDE the prior box and finite (the only
+// points a Metropolis step can accept): T>=Tmin>0 so every Planck argument is positive, and the
+// power-law bases are launch constants whose logarithms the host precomputed.  Same formulas as
+// the exact path below, transcendental kernels from fastmath.hpp; differences vs the reference
+// stay at the 1e-15 level (tests/test_sed_gpu.py).  THICK keeps the exact path (its power-law
+// base depends on the parameter nu0).
+template <int MODEL>
+__device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands& B,
+                                                  const SedConsts& k, double* derived) {
+  if (derived) { derived[0] = __builtin_nan(""); derived[1] = derived[0]; }
+  if constexpr (MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA ||
+                MODEL == MI355_SED_THICK_LOGA) {
+    const double A = (MODEL == MI355_SED_M1N) ? th[0] : exp10_fast(th[0]);
+    const double T = th[2], e3 = 3.0 + th[1];
+    const double rT = 1.0 / T;
+    const double en = expm1_fast(div_rcp(k.hk_nub, T, rT));
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double x = div_rcp(B.hnu(j), T, rT);
+      const double g = div_fast(pow_prelog(e3, B.lhi(j), B.llo(j)) * en, expm1_fast(x));
+      const double r = B.d(j) - A * g;
+      chi2 = fma(r * B.w(j), r, chi2);
+    }
+    return -0.5 * chi2;
+  } else if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+    const bool lg = (MODEL == MI355_SED_M2N_LOGA);
+    const double A1 = lg ? exp10_fast(th[0]) : th[0];
+    const double A2 = lg ? exp10_fast(th[3]) : th[3];
+    const double T1 = th[2], T2 = th[5];
+    const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
+    const double rT1 = 1.0 / T1, rT2 = 1.0 / T2;
+    const double en1 = expm1_fast(div_rcp(k.hk_nub, T1, rT1));
+    const double en2 = expm1_fast(div_rcp(k.hk_nub, T2, rT2));
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
+      const double g1 = div_fast(pow_prelog(e1, lh, ll) * en1, expm1_fast(div_rcp(hn, T1, rT1)));
+      const double g2 = div_fast(pow_prelog(e2, lh, ll) * en2, expm1_fast(div_rcp(hn, T2, rT2)));
+      const double r = B.d(j) - fma(A2, g2, A1 * g1);
+      chi2 = fma(r * B.w(j), r, chi2);
+    }
+    return -0.5 * chi2;
+  } else if constexpr (MODEL == MI355_SED_M1) {
+    const double T = th[1], e3 = 3.0 + th[0];
+    const double pre = k.prefac * pow_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
+    const double rT = 1.0 / T;
+    double FNiF = 0.0, FNid = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double x = div_rcp(B.hnu(j), T, rT);
+      const double g = div_fast(pre * pow_prelog(e3, B.lhi(j), B.llo(j)), expm1_fast(x));
+      const double gw = g * B.w(j);
+      FNiF = fma(gw, g, FNiF);
+      FNid = fma(gw, B.d(j), FNid);
+    }
+    const double amp = FNid / FNiF;
+    if (derived) derived[0] = amp;
+    return 0.5 * FNid * amp;
+  } else {
+    return sed_lnlike<MODEL>(th, B, k, derived);
+  }
+}
+
+// ---- likelihood, exact path --------------------------------------------------------------------
+// Returns like.lnLike(theta) WITHOUT the prior for ANY theta, with the reference's IEEE edge
+// behaviour (overflow -> inf -> 0 flux, NaN propagation).  derived[0..1] receive the ML amplitudes
+// of the marginalised likelihoods (NaN otherwise) when derived != nullptr.
+template <int MODEL>
+__device__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& k,
+                             double* derived) {
   if (derived) { derived[0] = __builtin_nan(""); derived[1] = derived[0]; }
 
   if constexpr (MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA ||
@@ -185,4 +266,15 @@ __device__ __forceinline__ double sed_lnlike(const double* th, const Bands& B, c
   }
 }
 
+}  // namespace mi355
+
+namespace mi355 {
+// What every caller uses: the fast path where it is valid, the exact path elsewhere.
+template <int MODEL>
+__device__ __forceinline__ double sed_lnlike_auto(const double* th, double prior, const Bands& B,
+                                                  const SedConsts& k, double* derived) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  if (prior > 0.0 && all_finite<P>(th)) return sed_lnlike_fast<MODEL>(th, B, k, derived);
+  return sed_lnlike<MODEL>(th, B, k, derived);
+}
 }  // namespace mi355

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
   for (int i = 0; i < P; ++i) th[i] = theta[i * n_eval + e];
   Bands B{smem + (s - s_first) * stride, nbm, nb[s]};
   double der[2];
-  const double v = sed_lnlike<MODEL>(th, B, k, derived ? der : nullptr);
+  const double v = sed_lnlike_auto<MODEL>(th, sed_prior<MODEL>(th, k), B, k, derived ? der : nullptr);
   lnl[e] = v;
   if (derived) {
     derived[e] = der[0];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
   }
   double lp = __builtin_nan("");
   if (!flag) {
-    lp = sed_lnlike<MODEL>(th, B, a.k, nullptr);
+    lp = sed_lnlike_auto<MODEL>(th, prior, B, a.k, nullptr);
     if (prior != 1.0) lp += log(prior);                   // MCMC.py:177
   }
 #pragma unroll
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_run(MhArgs a) {
     const double prior = sed_prior<MODEL>(nw, a.k);
     bool accepted = false;
     double next = lnPr;
-    if (prior > 0.0) {
-      double v = sed_lnlike<MODEL>(nw, B, a.k, nullptr);
+    if (prior > 0.0 && all_finite<P>(nw)) {
+      double v = sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         if (prior != 1.0) v += log(prior);                 // :250

@@ -1,0 +1,91 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+(source, chain) pairs are independent Markov chains, so the step loop needs no communication.
+Two layouts:
+  * source-sharded: rank r owns sources shard_range(S, r, W) and all their chains - no collective.
+  * chain-sharded : every rank holds all S sources and its own C chains of each; Gelman-Rubin
+    R-hat (MCMC/convergence.py:58-87) then needs per-source sums over all W*C chains:
+    two all-reduces of [P,S] and [2,P,S] float64, off the step loop.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous balanced shard [lo, hi) of n units for `rank` of `world`."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Join the job torchrun / torch.distributed.run started (RANK, WORLD_SIZE, MASTER_*).
+    Returns (rank, world, local_rank).  World size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_sum_(t, group=None):
+    if _world(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None):
+    """Chain-sharded Gelman-Rubin.
+
+    partial(pass_, gmean, out): fill `out` with this rank's sums over its C_local chains:
+         pass 0: out[P,S] = sum_c mean_c ;  pass 1: out[2,P,S] = (sum_c (mean_c-gmean)^2, sum_c var_c)
+    finish(sums, Ctot, out): out[P,S] = sqrt((W+B)/W)  (NaN where W<=0)
+    Both operate on torch float64 tensors resident on `device`; on a GPU they are the HIP
+    kernels behind mi355_rhat_partial_async / mi355_rhat_finish_async.  Centred second pass:
+    sum(mean^2) - (sum mean)^2/C would cancel catastrophically in FP64.
+    Returns (rhat [S,P] tensor, Ctot)."""
+    W = _world(group)
+    Ctot = torch.tensor([float(C_local)], dtype=torch.float64, device=device)
+    allreduce_sum_(Ctot, group)
+    Ctot = int(round(float(Ctot.item())))
+    s0 = torch.empty((P, S), dtype=torch.float64, device=device)
+    partial(0, None, s0)
+    allreduce_sum_(s0, group)
+    gmean = s0 / float(Ctot)
+    s1 = torch.empty((2, P, S), dtype=torch.float64, device=device)
+    partial(1, gmean, s1)
+    allreduce_sum_(s1, group)
+    out = torch.empty((P, S), dtype=torch.float64, device=device)
+    finish(s1, Ctot, out)
+    return out.t().contiguous(), Ctot
+
+
+def engine_rhat(engine, group=None):
+    """R-hat of every loaded source over the chains of all ranks in `group` (chain-sharded
+    layout); with one rank this equals Engine.rhat().  Returns a [S,P] CUDA tensor."""
+    device = torch.device("cuda", engine.device)
+
+    def partial(pass_, gmean, out):
+        torch.cuda.current_stream(device).synchronize()      # gmean written by torch
+        engine.rhat_partial(pass_, out.data_ptr(), gmean.data_ptr() if gmean is not None else None)
+        engine.sync()                                         # engine stream -> visible to torch
+
+    def finish(sums, Ctot, out):
+        torch.cuda.current_stream(device).synchronize()
+        engine.rhat_finish(sums.data_ptr(), Ctot, out.data_ptr())
+        engine.sync()
+
+    rhat, _ = gelman_rubin_allreduce(partial, finish, engine.C, engine.P, engine.S, device, group)
+    return rhat

@@ -59,6 +59,11 @@ class Engine:
     def stream(self):
         return self.lib.mi355_stream(self._h)
 
+    @property
+    def last_kernel_ms(self):
+        """HIP-event duration of the main kernel of the last mh_run / sed_lnlike call."""
+        return float(self.lib.mi355_last_kernel_ms(self._h))
+
     def sync(self):
         check(self.lib.mi355_sync(self._h))
 
