@@ -153,6 +153,12 @@ int mi355_mh_adapt(mi355_ctx* ctx, double fac, int32_t random_restart);
 int mi355_rng_dump(mi355_ctx* ctx, int64_t step0, int64_t nsteps, int64_t N, int32_t npn,
                    double* normals, double* uniforms);
 
+/* Evaluate one of the library's own FP64 kernels elementwise on host arrays (diagnostic, used by
+ * the accuracy tests): fn 0 exp(a), 1 expm1(a), 2 exp(a*(b+c)) with b+c a double-double
+ * logarithm (= base^a), 3 a/b, 4 10^a.  Inputs not used by fn may be null. */
+int mi355_math_probe(mi355_ctx* ctx, int32_t fn, int64_t n, const double* a, const double* b,
+                     const double* c, double* out);
+
 /* ---- Gelman-Rubin: MCMC/convergence.py:58-87 -------------------------------------------- */
 /* Per-source partial sums over this context's C chains, for an all-reduce across GPUs that
  * hold different chains of the same sources (chain-sharded layout).  dev buffers:

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mi355_mh_adapt": (C.c_int, [C.c_void_p, C.c_double, C.c_int32]),
     "mi355_rng_dump": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p,
                                  c_double_p]),
+    "mi355_math_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p,
+                                   c_double_p]),
     "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mi355_rhat": (C.c_int, [C.c_void_p, c_double_p]),

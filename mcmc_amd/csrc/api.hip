@@ -624,6 +624,29 @@ int mi355_rng_dump(mi355_ctx* c, int64_t step0, int64_t nsteps, int64_t N, int32
   return 0;
 }
 
+int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
+                     const double* cc, double* out) {
+  MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
+  MI355_REQUIRE(fn >= 0 && fn <= 4, "mi355_math_probe: unknown function %d", fn);
+  MI355_REQUIRE((fn != 2 && fn != 3) || b, "mi355_math_probe: b required");
+  MI355_REQUIRE(fn != 2 || cc, "mi355_math_probe: c required");
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t nn = static_cast<size_t>(n);
+  if (c->scratch_a.alloc(nn * 3) || c->scratch_b.alloc(nn)) return -2;
+  double* da = c->scratch_a.p;
+  double* db = da + nn;
+  double* dc = db + nn;
+  MI355_HIP(hipMemcpyAsync(da, a, nn * 8, hipMemcpyHostToDevice, c->stream));
+  if (b) MI355_HIP(hipMemcpyAsync(db, b, nn * 8, hipMemcpyHostToDevice, c->stream));
+  if (cc) MI355_HIP(hipMemcpyAsync(dc, cc, nn * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_math_probe, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
+                     c->stream, fn, n, da, db, dc, c->scratch_b.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(out, c->scratch_b.p, nn * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int mi355_rhat_partial_async(mi355_ctx* c, int32_t pass, const double* gmean_dev, double* sums_dev) {
   MI355_REQUIRE(c && c->mh_ready, "mi355_rhat: chains not initialised");
   MI355_REQUIRE(c->nsamp > 0, "mi355_rhat: no samples accumulated yet");

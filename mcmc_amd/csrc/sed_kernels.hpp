@@ -348,6 +348,21 @@ __global__ void k_rng_dump(uint64_t seed, int64_t step0, int64_t nsteps, int64_t
   uniforms[i] = philox_uniform(seed, RNG_UNIFORM, n, step);
 }
 
+__global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b, const double* c,
+                             double* out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v;
+  switch (fn) {
+    case 0: v = exp_fast(a[i]); break;
+    case 1: v = expm1_fast(a[i]); break;
+    case 2: v = pow_prelog(a[i], b[i], c[i]); break;
+    case 3: v = div_fast(a[i], b[i]); break;
+    default: v = exp10_fast(a[i]); break;
+  }
+  out[i] = v;
+}
+
 // ---- layout helpers -----------------------------------------------------------------------
 // in [rows][cols] -> out [cols][rows]
 __global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int64_t rows,

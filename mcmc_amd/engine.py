@@ -201,6 +201,14 @@ class Engine:
         check(self.lib.mi355_rng_dump(self._h, int(step0), int(nsteps), int(N), int(npn), _dp(z), _dp(u)))
         return z, u
 
+    def math_probe(self, fn, a, b=None, c=None):
+        a = _f64(a)
+        b = _f64(b, a.shape) if b is not None else None
+        c = _f64(c, a.shape) if c is not None else None
+        out = np.empty_like(a)
+        check(self.lib.mi355_math_probe(self._h, int(fn), a.size, _dp(a), _dp(b), _dp(c), _dp(out)))
+        return out
+
     # ---- Gelman-Rubin ----------------------------------------------------------------------
     def rhat(self):
         out = np.empty((self.S, self.P))

@@ -1,0 +1,83 @@
+"""Accuracy of the library's own FP64 transcendental kernels (mcmc_amd/csrc/fastmath.hpp)
+against mpmath, in units in the last place, on the domains the SED models use."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+mp = pytest.importorskip("mpmath")
+mp.mp.prec = 200
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from mcmc_amd import Engine
+    e = Engine(device=0)
+    yield e
+    e.close()
+
+
+def ulp_err(got, exact):
+    """max |got - exact| / ulp(exact) with exact a list of mpf."""
+    worst = 0.0
+    for g, e in zip(got, exact):
+        ef = float(e)
+        if ef == 0.0 or not np.isfinite(ef):
+            assert g == ef
+            continue
+        u = np.spacing(abs(ef))
+        worst = max(worst, float(abs(mp.mpf(float(g)) - e) / mp.mpf(float(u))))
+    return worst
+
+
+def test_expm1_planck_arguments(eng):
+    rng = np.random.default_rng(0)
+    # x = h nu / kT over the prior box: 1e-3 .. 690, plus tiny / negative / clamped edges
+    x = np.concatenate([10 ** rng.uniform(-3, np.log10(689.0), 4000), rng.uniform(-39, 0, 500),
+                        [1e-300, 1e-20, 0.0, 0.3465, 0.3467, 689.999, -39.9]])
+    got = eng.math_probe(1, x)
+    w = ulp_err(got, [mp.expm1(mp.mpf(float(v))) for v in x])
+    print("expm1: max %.2f ulp" % w)
+    assert w <= 2.0
+    # beyond the clamp the value saturates (flux underflows to ~1e-299 instead of exactly 0)
+    assert eng.math_probe(1, np.array([700.0, 1e6]))[0] == eng.math_probe(1, np.array([690.0]))[0]
+
+
+def test_exp_and_exp10(eng):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-680, 680, 3000), rng.uniform(-1, 1, 1000), [0.0]])
+    w = ulp_err(eng.math_probe(0, x), [mp.exp(mp.mpf(float(v))) for v in x])
+    print("exp: max %.2f ulp" % w)
+    assert w <= 1.5
+    y = rng.uniform(-290, 290, 3000)
+    w = ulp_err(eng.math_probe(4, y), [mp.power(10, mp.mpf(float(v))) for v in y])
+    print("exp10: max %.2f ulp" % w)
+    assert w <= 1.5
+
+
+def test_pow_with_precomputed_log(eng):
+    """base^e with ln(base) stored as a double-double (what mi355_sed_load precomputes):
+    bases nu/nu_b in 0.05..60, exponents 3+beta in 3..6."""
+    rng = np.random.default_rng(2)
+    base = 10 ** rng.uniform(np.log10(0.05), np.log10(60), 4000)
+    e = rng.uniform(3.0, 6.0, 4000)
+    lhi = np.empty_like(base)
+    llo = np.empty_like(base)
+    for i, b in enumerate(base):
+        l = mp.log(mp.mpf(float(b)))
+        lhi[i] = float(l)
+        llo[i] = float(l - mp.mpf(lhi[i]))
+    w = ulp_err(eng.math_probe(2, e, lhi, llo),
+                [mp.power(mp.mpf(float(b)), mp.mpf(float(x))) for b, x in zip(base, e)])
+    print("pow: max %.2f ulp" % w)
+    assert w <= 1.5
+
+
+def test_newton_division(eng):
+    rng = np.random.default_rng(3)
+    a = 10 ** rng.uniform(-100, 100, 5000) * rng.choice([-1, 1], 5000)
+    b = 10 ** rng.uniform(-100, 100, 5000)
+    got = eng.math_probe(3, a, b)
+    ref = a / b
+    ulps = np.abs(got - ref) / np.spacing(np.abs(ref))
+    print("div: max %.2f ulp, inexact fraction %.2e" % (ulps.max(), np.mean(ulps > 0)))
+    assert ulps.max() <= 1.0
