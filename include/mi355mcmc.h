@@ -93,11 +93,23 @@ int mi355_sed_lnlike(mi355_ctx* ctx, int64_t s0, int64_t ns, int32_t C, const do
  * derived_dev nullable [2, ns*C].  Asynchronous on the context stream. */
 int mi355_sed_lnlike_dev_async(mi355_ctx* ctx, int64_t s0, int64_t ns, int32_t C,
                                const double* theta_dev, double* lnL_dev, double* derived_dev);
+/* model(*theta).at_nu(nu) (model.py at_nu/at methods): flux of n parameter vectors (host [n,P])
+ * at nnu frequencies (host [nnu], rest-frame GHz) -> out host [n, nnu, ncol], ncol = 2 for
+ * submmModel2 (one column per component, model.py:176-182) and 1 otherwise. */
+int mi355_sed_flux(mi355_ctx* ctx, int64_t n, const double* theta, int64_t nnu, const double* nu,
+                   double* out);
 /* model.prior(*theta) (model.py prior classmethods) and model.package(theta)
  * (model.py:192-196,439-443,510-514) for n flat vectors: host [n,P] -> prior[n], packaged[n,P]
  * (either output nullable). */
 int mi355_sed_prior_package(mi355_ctx* ctx, int64_t n, const double* theta, double* prior,
                             double* packaged);
+
+/* ---- GaussianData: MCMC/GaussianData.py:31-64 ------------------------------------------ */
+/* quadform(A,B) = A^T N^-1 B with N = diag(sig2), for m rows at once: host A [m,n];
+ * B host [m,n] (b_rows=m), [n] (b_rows=1, shared by all rows) or null (= A); sig2 host [n]
+ * (nsig=n) or scalar (nsig=1); out host [m].  chi2(vec) is quadform(d-vec). */
+int mi355_gauss_quadform(mi355_ctx* ctx, int64_t m, int64_t n, const double* A, const double* B,
+                         int64_t b_rows, const double* sig2, int64_t nsig, double* out);
 
 /* ---- Metropolis-Hastings: MCMC/MCMC.py, MCMC/Proposal.py -------------------------------- */
 /* Create C chains per loaded source (N = S*C chains) = N instances of
@@ -128,6 +140,9 @@ int mi355_mh_run(mi355_ctx* ctx, int64_t nsteps, int32_t thin, const double* inj
  * accept [S,C,nblock]. */
 int mi355_mh_moments(mi355_ctx* ctx, double* mean, double* var, int64_t* naccept,
                      int64_t* accept, double* lnPr, double* theta);
+/* Current proposal widths prop.sigmas of every chain (they differ per chain after
+ * mi355_mh_adapt): host [S,C,P]. */
+int mi355_mh_sigmas(mi355_ctx* ctx, double* sigma);
 /* Philox stream position of the context: which=0 the global step counter (normal index =
  * step*npn + rank, uniform index = step), which=1 the stage counter (number of init/adapt calls
  * so far; keys the start-randomisation stream).  Counter-based draws make a resumed run exact:
@@ -170,6 +185,11 @@ int mi355_rhat_partial_async(mi355_ctx* ctx, int32_t pass, const double* gmean_d
 /* Rhat = sqrt((W+B)/W), W = sum var / Ctot, B = sum (mean-gmean)^2 / (Ctot-1); NaN where W<=0
  * (the reference drops those parameters, convergence.py:81-83).  rhat_dev [P, S]. */
 int mi355_rhat_finish_async(mi355_ctx* ctx, const double* sums_dev, int64_t Ctot, double* rhat_dev);
+/* gelmanrubin_MCMC(MCMCs) (convergence.py:58-87) from per-chain moments handed over by the host:
+ * means, vars host [nchain, P] (vars = stdev**2, ddof=0) -> rhat host [P], NaN where the mean
+ * within-chain variance is not positive.  Needs no catalogue. */
+int mi355_gelman_rubin(mi355_ctx* ctx, int32_t nchain, int32_t P, const double* means,
+                       const double* vars, double* rhat);
 /* Single-GPU convenience: all C chains are local.  rhat host [S, P]. */
 int mi355_rhat(mi355_ctx* ctx, double* rhat);
 

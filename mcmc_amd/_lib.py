@@ -41,12 +41,14 @@ SIGNATURES = {
                                    c_double_p, c_double_p]),
     "mi355_sed_lnlike_dev_async": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
+    "mi355_sed_flux": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "mi355_sed_prior_package": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "mi355_mh_init": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int32,
                                 c_int32_p, C.c_int32, C.c_int32]),
     "mi355_mh_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_double_p, c_double_p]),
     "mi355_mh_moments": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int64_p, c_int64_p,
                                    c_double_p, c_double_p]),
+    "mi355_mh_sigmas": (C.c_int, [C.c_void_p, c_double_p]),
     "mi355_mh_stream_pos": (C.c_int64, [C.c_void_p, C.c_int32]),
     "mi355_mh_set_stream_pos": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "mi355_mh_nsamples": (C.c_int64, [C.c_void_p]),
@@ -55,10 +57,13 @@ SIGNATURES = {
     "mi355_mh_adapt": (C.c_int, [C.c_void_p, C.c_double, C.c_int32]),
     "mi355_rng_dump": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p,
                                  c_double_p]),
+    "mi355_gauss_quadform": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_double_p,
+                                       C.c_int64, c_double_p, C.c_int64, c_double_p]),
     "mi355_math_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p,
                                    c_double_p]),
     "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mi355_gelman_rubin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "mi355_rhat": (C.c_int, [C.c_void_p, c_double_p]),
 }
 

@@ -88,6 +88,18 @@ struct LaunchPriorPackage {
 };
 
 template <int M>
+struct LaunchFlux {
+  static int run(mi355_ctx* c, int64_t n, const double* theta, int64_t nnu, const double* nu,
+                 double* out) {
+    const unsigned grid = static_cast<unsigned>(ceil_div(n * nnu, kBlockThreads));
+    hipLaunchKernelGGL(k_sed_flux<M>, dim3(grid), dim3(kBlockThreads), 0, c->stream, n, theta, nnu,
+                       nu, out, c->kc);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
+};
+
+template <int M>
 struct LaunchStart {
   static int run(mi355_ctx* c, const MhArgs& a) {
     size_t lds = 0;
@@ -363,6 +375,26 @@ int mi355_sed_lnlike(mi355_ctx* c, int64_t s0, int64_t ns, int32_t C, const doub
   return 0;
 }
 
+int mi355_sed_flux(mi355_ctx* c, int64_t n, const double* theta, int64_t nnu, const double* nu,
+                   double* out) {
+  MI355_REQUIRE(c && c->sed_loaded, "mi355_sed_flux: no model loaded");
+  MI355_REQUIRE(theta && nu && out && n > 0 && nnu > 0, "mi355_sed_flux: bad argument");
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->P;
+  const int nc = (c->model.model == MI355_SED_M2) ? 2 : 1;
+  const size_t nt = static_cast<size_t>(n) * P, no = static_cast<size_t>(n) * nnu * nc;
+  if (c->scratch_a.alloc(nt + nnu) || c->scratch_b.alloc(no)) return -2;
+  MI355_HIP(hipMemcpyAsync(c->scratch_a.p, theta, nt * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(c->scratch_a.p + nt, nu, static_cast<size_t>(nnu) * 8,
+                           hipMemcpyHostToDevice, c->stream));
+  int rc = dispatch_model<LaunchFlux>(c->model.model, c, n, c->scratch_a.p, nnu,
+                                      c->scratch_a.p + nt, c->scratch_b.p);
+  if (rc) return rc;
+  MI355_HIP(hipMemcpyAsync(out, c->scratch_b.p, no * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int mi355_sed_prior_package(mi355_ctx* c, int64_t n, const double* theta, double* prior,
                             double* packaged) {
   MI355_REQUIRE(c && c->sed_loaded, "mi355_sed_prior_package: no model loaded");
@@ -562,6 +594,12 @@ int mi355_mh_moments(mi355_ctx* c, double* mean, double* var, int64_t* naccept, 
   return 0;
 }
 
+int mi355_mh_sigmas(mi355_ctx* c, double* sigma) {
+  MI355_REQUIRE(c && c->mh_ready && sigma, "mi355_mh_sigmas: chains not initialised");
+  MI355_HIP(hipSetDevice(c->device));
+  return download_param(c, c->sigma.p, sigma, 1.0);
+}
+
 int mi355_mh_trace(mi355_ctx* c, double* samples, double* lnPr, uint8_t* accepted) {
   MI355_REQUIRE(c && c->mh_ready, "mi355_mh_trace: chains not initialised");
   MI355_REQUIRE(c->nkeep > 0, "mi355_mh_trace: the last mi355_mh_run kept no trace (thin=0)");
@@ -624,6 +662,33 @@ int mi355_rng_dump(mi355_ctx* c, int64_t step0, int64_t nsteps, int64_t N, int32
   return 0;
 }
 
+int mi355_gauss_quadform(mi355_ctx* c, int64_t m, int64_t n, const double* A, const double* B,
+                         int64_t b_rows, const double* sig2, int64_t nsig, double* out) {
+  MI355_REQUIRE(c && A && sig2 && out, "mi355_gauss_quadform: null argument");
+  MI355_REQUIRE(m > 0 && n > 0, "mi355_gauss_quadform: empty input");
+  MI355_REQUIRE(nsig == n || nsig == 1, "DataSizeError: %lld data points but %lld sigmas "
+                "[GaussianData.py:21-26]", static_cast<long long>(n), static_cast<long long>(nsig));
+  MI355_REQUIRE(!B || b_rows == m || b_rows == 1, "mi355_gauss_quadform: b_rows must be m or 1");
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t mn = static_cast<size_t>(m) * n;
+  const size_t bn = B ? static_cast<size_t>(b_rows) * n : 0;
+  if (c->scratch_a.alloc(mn + bn + nsig) || c->scratch_b.alloc(static_cast<size_t>(m))) return -2;
+  double* dA = c->scratch_a.p;
+  double* dB = B ? dA + mn : nullptr;
+  double* dS = dA + mn + bn;
+  MI355_HIP(hipMemcpyAsync(dA, A, mn * 8, hipMemcpyHostToDevice, c->stream));
+  if (B) MI355_HIP(hipMemcpyAsync(dB, B, bn * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(dS, sig2, static_cast<size_t>(nsig) * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gauss_quadform, dim3(static_cast<unsigned>(m)), dim3(kBlockThreads), 0,
+                     c->stream, n, dA, dB, static_cast<int64_t>(b_rows == 1 ? 0 : n), dS,
+                     nsig == 1 ? 1 : 0, c->scratch_b.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(out, c->scratch_b.p, static_cast<size_t>(m) * 8, hipMemcpyDeviceToHost,
+                           c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* cc, double* out) {
   MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
@@ -669,6 +734,25 @@ int mi355_rhat_finish_async(mi355_ctx* c, const double* sums_dev, int64_t Ctot, 
   hipLaunchKernelGGL(k_rhat_finish, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
                      c->stream, n, static_cast<double>(Ctot), sums_dev, rhat_dev);
   MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+int mi355_gelman_rubin(mi355_ctx* c, int32_t nchain, int32_t P, const double* means,
+                       const double* vars, double* rhat) {
+  MI355_REQUIRE(c && means && vars && rhat, "mi355_gelman_rubin: null argument");
+  MI355_REQUIRE(nchain >= 2 && P > 0, "Gelman-Rubin needs at least 2 chains (got %d)", nchain);
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t n = static_cast<size_t>(nchain) * P;
+  if (c->scratch_a.alloc(2 * n + P)) return -2;
+  double* dm = c->scratch_a.p;
+  double* dv = dm + n;
+  double* dr = dv + n;
+  MI355_HIP(hipMemcpyAsync(dm, means, n * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(dv, vars, n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gelman_rubin, dim3((P + 63) / 64), dim3(64), 0, c->stream, nchain, P, dm, dv, dr);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(rhat, dr, static_cast<size_t>(P) * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -269,6 +269,37 @@ __device__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& 
 }  // namespace mi355
 
 namespace mi355 {
+// model(*theta).at_nu(nu) for one frequency, exact (OCML) arithmetic in the reference's order.
+// out[1] is only written for submmModel2 (two un-normalised components).
+template <int MODEL>
+__device__ void sed_flux(const double* th, double nu, const SedConsts& k, double* out) {
+  auto grey_n = [&](double beta, double T) {             // model.py:107-109
+    return pow(nu / k.nu_b, 3.0 + beta) * expm1(k.hk_nub / T) / expm1(k.h_over_k * nu / T);
+  };
+  auto grey_u = [&](double beta, double T) {             // model.py:111
+    return k.prefac * pow(k.nu_b, -beta) * pow(nu, 3.0 + beta) / expm1(k.h_over_k * nu / T);
+  };
+  if constexpr (MODEL == MI355_SED_M1N) {
+    out[0] = th[0] * grey_n(th[1], th[2]);
+  } else if constexpr (MODEL == MI355_SED_M1N_LOGA || MODEL == MI355_SED_THICK_LOGA) {
+    out[0] = pow(10.0, th[0]) * grey_n(th[1], th[2]);
+  } else if constexpr (MODEL == MI355_SED_M2N) {
+    out[0] = th[0] * grey_n(th[1], th[2]) + th[3] * grey_n(th[4], th[5]);
+  } else if constexpr (MODEL == MI355_SED_M2N_LOGA) {
+    out[0] = pow(10.0, th[0]) * grey_n(th[1], th[2]) + pow(10.0, th[3]) * grey_n(th[4], th[5]);
+  } else if constexpr (MODEL == MI355_SED_M1) {
+    out[0] = grey_u(th[0], th[1]);
+  } else if constexpr (MODEL == MI355_SED_M2) {
+    out[0] = grey_u(th[0], th[1]);
+    out[1] = grey_u(th[2], th[3]);
+  } else {                                               // model.py:649-652
+    const double tau = pow(nu / th[3] / k.nu_rescale, th[1]);
+    const double tau_b = pow(k.nu_b / th[3] / k.nu_rescale, th[1]);
+    const double bb = pow(nu / k.nu_b, 3.0) * expm1(k.hk_nub / th[2]) / expm1(k.h_over_k * nu / th[2]);
+    out[0] = th[0] * (1.0 - exp(-tau)) / (1.0 - exp(-tau_b)) * bb;
+  }
+}
+
 // What every caller uses: the fast path where it is valid, the exact path elsewhere.
 template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_auto(const double* th, double prior, const Bands& B,

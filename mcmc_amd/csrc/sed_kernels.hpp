@@ -112,6 +112,24 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_prior_package(
   }
 }
 
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads) void k_sed_flux(
+    int64_t n, const double* __restrict__ theta, int64_t nnu, const double* __restrict__ nu,
+    double* __restrict__ out, SedConsts k) {
+  constexpr int P = ModelTraits<MODEL>::P;
+  constexpr int NC = (MODEL == MI355_SED_M2) ? 2 : 1;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * nnu) return;
+  const int64_t it = e / nnu, in = e % nnu;
+  double th[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) th[i] = theta[it * P + i];
+  double f[2] = {0.0, 0.0};
+  sed_flux<MODEL>(th, nu[in], k, f);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) out[e * NC + c] = f[c];
+}
+
 // ---- chain start (setStart, MCMC.py:138-187) and restart from moments (newMCMC, :343-413) ---
 template <int MODEL>
 __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
@@ -363,6 +381,27 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
   out[i] = v;
 }
 
+// ---- GaussianData.quadform (GaussianData.py:31-53): one 256-thread block per row ------------
+__global__ __launch_bounds__(kBlockThreads) void k_gauss_quadform(
+    int64_t n, const double* __restrict__ A, const double* __restrict__ B, int64_t b_stride,
+    const double* __restrict__ sig2, int sig_is_scalar, double* __restrict__ out) {
+  __shared__ double part[kBlockThreads / 64];
+  const double* a = A + static_cast<int64_t>(blockIdx.x) * n;
+  const double* b = B ? B + static_cast<int64_t>(blockIdx.x) * b_stride : a;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+    acc = fma(a[i] / sig2[sig_is_scalar ? 0 : i], b[i], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kBlockThreads / 64; ++w) t += part[w];
+    out[blockIdx.x] = t;
+  }
+}
+
 // ---- layout helpers -----------------------------------------------------------------------
 // in [rows][cols] -> out [cols][rows]
 __global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int64_t rows,
@@ -418,6 +457,26 @@ __global__ void k_rhat_finish(int64_t n, double Ctot, const double* __restrict__
   const double within = sums[n + i] / Ctot;              // mean of the chain variances, :77
   const double between = sums[i] / (Ctot - 1.0);         // ddof=1 variance of the means, :78
   rhat[i] = (within > 0.0) ? sqrt((within + between) / within) : __builtin_nan("");   // :81-85
+}
+
+// one thread per parameter; means, vars [nchain][P]
+__global__ void k_gelman_rubin(int nchain, int P, const double* __restrict__ means,
+                               const double* __restrict__ vars, double* __restrict__ rhat) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double sm = 0.0, sv = 0.0;
+  for (int c = 0; c < nchain; ++c) {
+    sm += means[c * P + p];
+    sv += vars[c * P + p];
+  }
+  const double g = sm / nchain, within = sv / nchain;
+  double ss = 0.0;
+  for (int c = 0; c < nchain; ++c) {
+    const double dm = means[c * P + p] - g;
+    ss += dm * dm;
+  }
+  const double between = ss / (nchain - 1);
+  rhat[p] = (within > 0.0) ? sqrt((within + between) / within) : __builtin_nan("");
 }
 
 __global__ void k_scale(int64_t n, double f, double* x) {

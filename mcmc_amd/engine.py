@@ -110,6 +110,19 @@ class Engine:
                                                   C.c_void_p(theta_ptr), C.c_void_p(lnl_ptr),
                                                   C.c_void_p(derived_ptr) if derived_ptr else None))
 
+    def sed_flux(self, theta, nu):
+        """theta [n,P] (or [P]), nu [nnu] -> flux [n, nnu] ([n, nnu, 2] for submmModel2)."""
+        theta = _f64(theta)
+        single = theta.ndim == 1
+        th = theta.reshape(-1, self.P)
+        nu = _f64(nu).reshape(-1)
+        nc = 2 if int(self.model.model) == MODEL_IDS["M2"] else 1
+        out = np.empty((th.shape[0], nu.size, nc))
+        check(self.lib.mi355_sed_flux(self._h, th.shape[0], _dp(th), nu.size, _dp(nu), _dp(out)))
+        if nc == 1:
+            out = out[..., 0]
+        return out[0] if single else out
+
     def sed_prior_package(self, theta):
         theta = _f64(theta)
         flat = theta.reshape(-1, self.P)
@@ -168,6 +181,11 @@ class Engine:
             _dp(out["lnPr"]), _dp(out["theta"])))
         return out
 
+    def mh_sigmas(self):
+        out = np.empty((self.S, self.C, self.P))
+        check(self.lib.mi355_mh_sigmas(self._h, _dp(out)))
+        return out
+
     @property
     def nsamples(self):
         return int(self.lib.mi355_mh_nsamples(self._h))
@@ -201,6 +219,23 @@ class Engine:
         check(self.lib.mi355_rng_dump(self._h, int(step0), int(nsteps), int(N), int(npn), _dp(z), _dp(u)))
         return z, u
 
+    def gauss_quadform(self, A, sig2, B=None):
+        """rows of A [m,n] (or one vector [n]) -> A^T N^-1 B per row, N = diag(sig2)."""
+        A = _f64(A)
+        single = A.ndim == 1
+        A2 = A.reshape(1, -1) if single else A
+        m, n = A2.shape
+        sig2 = _f64(sig2).reshape(-1)
+        b_rows = 0
+        if B is not None:
+            B = _f64(B)
+            B = B.reshape(-1, n)
+            b_rows = B.shape[0]
+        out = np.empty(m)
+        check(self.lib.mi355_gauss_quadform(self._h, m, n, _dp(A2), _dp(B), b_rows, _dp(sig2),
+                                            sig2.size, _dp(out)))
+        return float(out[0]) if single else out
+
     def math_probe(self, fn, a, b=None, c=None):
         a = _f64(a)
         b = _f64(b, a.shape) if b is not None else None
@@ -215,6 +250,14 @@ class Engine:
         check(self.lib.mi355_rhat(self._h, _dp(out)))
         return out
 
+    def gelman_rubin(self, means, variances):
+        means = _f64(means)
+        variances = _f64(variances, means.shape)
+        out = np.empty(means.shape[1])
+        check(self.lib.mi355_gelman_rubin(self._h, means.shape[0], means.shape[1], _dp(means),
+                                          _dp(variances), _dp(out)))
+        return out
+
     def rhat_partial(self, pass_, sums_ptr, gmean_ptr=None):
         check(self.lib.mi355_rhat_partial_async(self._h, int(pass_),
                                                 C.c_void_p(gmean_ptr) if gmean_ptr else None,
@@ -225,4 +268,14 @@ class Engine:
                                                C.c_void_p(rhat_ptr)))
 
 
-__all__ = ["Engine", "Mi355Error", "MODEL_IDS"]
+_DEFAULT = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine for stateless calls (GaussianData.quadform, probes)."""
+    if device not in _DEFAULT:
+        _DEFAULT[device] = Engine(device=device)
+    return _DEFAULT[device]
+
+
+__all__ = ["Engine", "Mi355Error", "MODEL_IDS", "default_engine"]
