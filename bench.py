@@ -27,6 +27,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 1342.0        # 2-comp, 8 bands, 1 transcendental = 32 FP64 FLOP
 PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vector FP64)
+# HBM bytes per chain per launch of k_mh_run<M2N>, from the PMC passes in
+# profiles/r1_bench_summary.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
+# State is read and written once per launch whatever the number of inner steps.
+HBM_BYTES_PER_CHAIN_LAUNCH = 415.7
 
 
 def cpu_baseline(nu, d, sig, seconds=12.0):
@@ -139,11 +143,13 @@ def main():
                    "layout": "chain-sharded, R-hat all-reduce per step" if world > 1 else "single GPU",
                    "adapt_steps": args.adapt},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS,
+                     "traffic": HBM_BYTES_PER_CHAIN_LAUNCH * S * C,
                      "kernel": "k_mh_run<M2N>", "kernel_ms": k_ms,
                      "note": "FP64 VALU (transcendental-bound); algorithmic FLOP = 1342 per MH step "
                              "(SURVEY 8d convention, 1 transcendental = 32 FLOP) x S*C*inner steps "
-                             "per launch; HBM traffic is ~1e-3 of the 8 TB/s roof"},
+                             "per launch; traffic = HBM bytes per launch from rocprofv3 PMC "
+                             "(profiles/r1_bench_summary.txt), ~0.5% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
