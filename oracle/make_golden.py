@@ -55,8 +55,20 @@ def load_reference():
     sys.modules["MCMC"] = pkg
     mods = {}
     for name in ["GaussianData", "Likelihood", "Proposal", "MCMC", "convergence",
-                 "submmSED.model", "submmSED.likelihood", "submmSED.data"]:
+                 "submmSED.model", "submmSED.likelihood", "submmSED.data",
+                 "ClData.ClData_CosmoMC", "binnedCl.binnedClLikelihood",
+                 "BeamFit.BeamModel", "BeamFit.OffsetNormalizedBeamModel",
+                 "BeamFit.NormalizedBeamLikelihood", "BeamFit.BeamData"]:
         mods[name] = importlib.import_module("MCMC." + name)
+    # binnedClModel.setBinning names `collections.Sequence` without importing collections
+    # (binnedClModel.py:205): give the module that namespace, nothing else.
+    import collections.abc
+    import builtins
+    builtins.collections = types.SimpleNamespace(Sequence=collections.abc.Sequence)
+    mods["binnedCl.binnedClModel"] = importlib.import_module("MCMC.binnedCl.binnedClModel")
+    del builtins.collections
+    mods["binnedCl.binnedClModel"].collections = types.SimpleNamespace(
+        Sequence=collections.abc.Sequence)
     # determinism: both constructors reseed the global RNG from OS entropy
     mods["MCMC"].seed = lambda *a, **k: None
     mods["Proposal"].seed = lambda *a, **k: None
@@ -92,9 +104,7 @@ class Injector:
         return self.uniforms[self.k - 1]
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    R = load_reference()
+def golden_sed(R):
     model, like_mod, data_mod = R["submmSED.model"], R["submmSED.likelihood"], R["submmSED.data"]
     MC, Prop, conv = R["MCMC"], R["Proposal"], R["convergence"]
     sha = ref_tree_sha()
@@ -346,6 +356,364 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sed_g4.npz"), **g4)
     print("sampler() stages:", [len(s.samples) for s in stages], "means", ana[0])
     print("wrote fixtures to", os.path.abspath(OUT), "ref sha", sha[:16])
+
+
+# ---------------------------------------------------------------------------------------------
+# G5: binnedCl / ClData band-power likelihood
+# ---------------------------------------------------------------------------------------------
+def _cl_inputs(rng, shape3, nb, lmax, nbins, pol, with_x, mixed_x, corr, calib, beam, diag=False):
+    """Synthetic inputs for one dataset + binning (plain arrays; nothing of the reference)."""
+    ell = np.arange(lmax + 1, dtype=np.float64)
+    nCl = 3 if pol else 1
+    bins = []
+    for iCl, nbin in enumerate(nbins[:nCl]):
+        edges = np.linspace(30 + 7 * iCl, lmax - 20 - 5 * iCl, nbin + 1).astype(int)
+        bins.append(np.stack([edges[:-1], edges[1:] - 1], axis=1))      # inclusive (lmin, lmax)
+    # the caller truncates the shape to the binning's own lmax (SURVEY App. B: setBinning does
+    # not truncate an ndarray under Py3); multipoles below the first bin keep the bare shape
+    mlmax = int(max(b.max() for b in bins))
+    shapefun = np.array(shape3[:nCl, :mlmax + 1], dtype=np.float64)
+    window = np.zeros((nb, 3, lmax + 1))
+    win_min = np.empty(nb, int)
+    win_max = np.empty(nb, int)
+    inc_pol = np.zeros(nb, bool)
+    kind = np.zeros(nb, int)
+    wedges = np.linspace(10, lmax + 40, nb + 1).astype(int)             # last windows overrun lmax
+    for i in range(nb):
+        lo, hi = wedges[i], wedges[i + 1] + 6
+        l = np.arange(lo, hi + 1, dtype=np.float64)
+        w = (l * (l + 1) / (2 * math.pi)) / (hi - lo + 1) * (1 + 0.3 * np.sin(l / 13.0 + i))
+        k = (i % 3) if (pol and i >= nb // 2) else 0
+        kind[i] = k
+        wfull = np.zeros(lmax + 61)
+        wfull[lo:hi + 1] = w
+        if k == 0:
+            window[i, 0] = wfull[:lmax + 1]
+        else:
+            inc_pol[i] = True
+            window[i, k] = wfull[:lmax + 1]
+            window[i, 0] = 0.02 * wfull[:lmax + 1]                      # small TT leakage term
+        win_min[i], win_max[i] = lo, hi                                 # win_max may exceed lmax
+    return dict(shapefun=shapefun, bins=bins, window=window, win_min=win_min, win_max=win_max,
+                inc_pol=inc_pol, kind=kind, nb=nb, lmax=lmax, pol=pol, with_x=with_x,
+                mixed_x=mixed_x, corr=corr, calib=calib, beam=beam, diag=diag)
+
+
+def golden_cl(R):
+    CD = R["ClData.ClData_CosmoMC"]
+    BM = R["binnedCl.binnedClModel"]
+    BL = R["binnedCl.binnedClLikelihood"]
+    MC, Prop = R["MCMC"], R["Proposal"]
+    import contextlib
+    import io
+    sha = ref_tree_sha()
+    rng = np.random.default_rng(4242)
+    tmp = np.fromfile(os.path.join(REF, "dat", "CarloClModel.dat"), sep=" ").reshape(-1, 6)
+    ells = tmp[:, 0].astype(int)
+    L = ells.max()
+    shape3 = np.zeros((3, L + 1))
+    shape3[0, ells] = tmp[:, 1]                       # TT   test_binnedCl.py:48-58
+    shape3[1, ells] = tmp[:, 3]                       # TE
+    shape3[2, ells] = tmp[:, 2]                       # EE
+
+    def build(inp, truth):
+        """reference objects for one (binning, dataset) pair"""
+        with contextlib.redirect_stdout(io.StringIO()):
+            BM.binnedClModel.setBinning([b for b in inp["bins"]], shapefun=inp["shapefun"],
+                                        doBlock=True)
+        nb = inp["nb"]
+        d = CD.ClData_CosmoMC()
+        d.name = "synthetic"
+        d.all_l_exact = False
+        d.num_points = nb
+        d.window, d.win_min, d.win_max = inp["window"], inp["win_min"], inp["win_max"]
+        d.has_pol = bool(inp["pol"])
+        d.inc_pol = inp["inc_pol"]
+        d.has_xfactors = False
+        d.has_corr_errors = not inp["diag"]
+        d.calib_uncertainty = inp["calib"]
+        d.beam_uncertain = inp["beam"] > 0
+        d.beam_err = inp["beam"] * (1 + np.arange(nb) / nb) if inp["beam"] > 0 else None
+        with np.errstate(all="ignore"):
+            Cl = BM.binnedClModel(truth)().copy()
+            bp = np.array([d.getWinBandpower(i, Cl) for i in range(nb)])
+        sig = 0.06 * np.abs(bp) + 0.01 * np.abs(bp).max()
+        A = rng.normal(size=(nb, nb))
+        Cn = A @ A.T
+        dg = np.sqrt(np.diag(Cn))
+        Cn = (1 - inp["corr"]) * np.eye(nb) + inp["corr"] * Cn / dg[:, None] / dg[None, :]
+        cov = Cn * sig[:, None] * sig[None, :]
+        cobs = bp + np.linalg.cholesky(cov) @ rng.normal(size=nb)
+        if inp["with_x"]:
+            has_x = (inp["kind"] == 0)                # offset lognormal only for TT bands
+            if inp["mixed_x"]:
+                has_x[::4] = False
+            x = np.where(has_x, 0.3 * np.abs(bp) + 1.0, 0.0)
+            f = np.where(has_x, cobs + x, 1.0)
+            d.obs = np.where(has_x, np.log(np.abs(cobs + x)), cobs)
+            ninv = np.linalg.inv(cov) * f[:, None] * f[None, :]     # ClData_bcp.py:192-210
+            d.xfactors, d.has_xfactor, d.has_xfactors = x, has_x, True
+            var = np.diag(cov) / f ** 2
+        else:
+            d.obs = cobs
+            ninv = np.linalg.inv(cov)
+            d.xfactors = d.has_xfactor = None
+            var = np.diag(cov).copy()
+        if inp["diag"]:
+            d.var, d.N_inv = var, None
+        else:
+            d.N_inv, d.var = ninv, None
+        return d
+
+    g = dict(ref_sha=sha)
+    cases = [
+        # name              nb  lmax nbins        pol    x      mixed  corr calib beam  diag
+        ("xfull",           12, 600, (8,),        False, True,  False, 0.3, 0.0,  0.0, False),
+        ("xcalib",          12, 600, (8,),        False, True,  False, 0.3, 0.05, 0.0, False),
+        ("xcalibbeam",      16, 700, (10,),       False, True,  True,  0.3, 0.05, 0.02, False),
+        ("xbeam",           12, 600, (8,),        False, True,  False, 0.2, 0.0,  0.03, False),
+        ("gauss_analytic",  12, 600, (8,),        False, False, False, 0.3, 0.05, 0.02, False),
+        ("gauss_calib",     12, 600, (8,),        False, False, False, 0.3, 0.04, 0.0, False),
+        ("gauss_beam",      12, 600, (8,),        False, False, False, 0.3, 0.0,  0.02, False),
+        ("gauss_diag",      12, 600, (8,),        False, False, False, 0.0, 0.05, 0.02, True),
+        ("x_diag_calib",    12, 600, (8,),        False, True,  True,  0.0, 0.05, 0.0, True),
+        ("pol",             18, 700, (8, 4, 4),   True,  True,  False, 0.3, 0.05, 0.0, False),
+        ("pol_gauss",       18, 700, (8, 4, 4),   True,  False, False, 0.2, 0.03, 0.01, False),
+        ("wide",            40, 900, (24,),       False, True,  False, 0.3, 0.0,  0.0, False),
+    ]
+    NQ = 20
+    for (name, nb, lmax, nbins, pol, wx, mx, corr, calib, beam, diag) in cases:
+        inp = _cl_inputs(rng, shape3, nb, lmax, nbins, pol, wx, mx, corr, calib, beam, diag)
+        npar = int(sum(nbins[:3 if pol else 1]))
+        truth = rng.uniform(0.8, 1.2, npar)
+        d = build(inp, truth)
+        like = BL.binnedClLikelihood(data=[d], model=BM.binnedClModel)
+        q = truth[None, :] * rng.uniform(0.7, 1.3, (NQ, npar))
+        q[0] = truth
+        q[3, 0] = -0.2                          # negative TT bin: prior 0, likelihood still defined
+        q[4] = -0.8 * truth                     # BP + x <= 0 on offset-lognormal bands -> -inf / NaN
+        if pol:
+            q[5, nbins[0]:nbins[0] + nbins[1]] *= -1.0     # negative TE is allowed (:129)
+        lnl = np.empty(NQ); pri = np.empty(NQ); neg = np.empty(NQ)
+        bps = np.empty((NQ, nb)); cls_ = []
+        with np.errstate(all="ignore"):
+            for t in range(NQ):
+                lnl[t] = like.lnLike(q[t])
+                pri[t] = BM.binnedClModel.prior(*q[t])
+                Cl = BM.binnedClModel(q[t])().copy()
+                neg[t] = d.calcLnLike(Cl)
+                bps[t] = [d.getWinBandpower(i, Cl) for i in range(nb)]
+                if t < 2:
+                    cls_.append(Cl)
+            delta = d.getdelta(bps[1].copy())
+            quad = d.getquadform(delta)
+            lin = d.getlinform(bps[1].copy())
+            # calcChisq (:262-265) hands getdelta a list, which fails for x-factor data;
+            # getchisq on the array is what calcLnLike's marginalisation loop calls (:338)
+            chisq = d.getchisq(bps[1].copy())
+        pre = "%s__" % name
+        for k in ("shapefun", "window", "win_min", "win_max", "inc_pol"):
+            g[pre + k] = inp[k]
+        for i, b in enumerate(inp["bins"]):
+            g[pre + "bins%d" % i] = b
+        g[pre + "nCl"] = len(inp["bins"])
+        g[pre + "obs"] = d.obs
+        g[pre + "N_inv"] = d.N_inv if d.N_inv is not None else np.zeros((0, 0))
+        g[pre + "var"] = d.var if d.var is not None else np.zeros(0)
+        g[pre + "xfactors"] = d.xfactors if d.xfactors is not None else np.zeros(0)
+        g[pre + "has_xfactor"] = d.has_xfactor if d.has_xfactor is not None else np.zeros(0, bool)
+        g[pre + "calib"] = calib
+        g[pre + "beam_err"] = d.beam_err if d.beam_err is not None else np.zeros(0)
+        g[pre + "has_pol"] = pol
+        g[pre + "q"] = q
+        g[pre + "lnl"] = lnl
+        g[pre + "prior"] = pri
+        g[pre + "neglnl"] = neg
+        g[pre + "bandpowers"] = bps
+        g[pre + "Cl"] = np.array(cls_)
+        g[pre + "delta1"] = delta
+        g[pre + "quad1"] = quad
+        g[pre + "lin1"] = lin
+        g[pre + "chisq1"] = chisq
+        g[pre + "BPnorm"] = np.concatenate([np.asarray(b) for b in BM.binnedClModel.BPnorm])
+        print("cl %-15s lnL(truth)=%r  lnL[4]=%r" % (name, lnl[0], lnl[4]))
+        if name == "xcalibbeam":
+            # two datasets in one likelihood: the sum over datasets (binnedClLikelihood.py:32)
+            inp2 = _cl_inputs(rng, shape3, 12, lmax, nbins, False, True, False, 0.25, 0.03, 0.0)
+            inp2["bins"], inp2["shapefun"] = inp["bins"], inp["shapefun"]
+            d2 = build(inp2, truth)
+            like2 = BL.binnedClLikelihood(data=[d, d2], model=BM.binnedClModel)
+            with np.errstate(all="ignore"):
+                g["two__lnl"] = np.array([like2.lnLike(q[t]) for t in range(NQ)])
+            for k in ("window", "win_min", "win_max", "inc_pol"):
+                g["two__" + k] = inp2[k]
+            g["two__obs"], g["two__N_inv"] = d2.obs, d2.N_inv
+            g["two__xfactors"], g["two__has_xfactor"] = d2.xfactors, d2.has_xfactor
+            g["two__calib"] = 0.03
+        if name == "xcalib":
+            # draw-injected chains: block stage, then newMCMC(rotateParams=True) and a
+            # Cholesky-correlated all-parameter stage (test_binnedCl.py:177 uses rotateParams)
+            r = np.random.default_rng(99)
+            nrows = 4000
+            inj = Injector(r.standard_normal((nrows, npar)), r.uniform(size=nrows))
+            Prop.normal = inj.normal
+            MC.uniform = inj.uniform
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                m0 = MC.MCMC(like, startProposal=np.full(npar, 0.05), startParams=truth.copy(),
+                             doBlock=True)
+                k_start = inj.k
+                m0.MC_append(400)
+                k1 = inj.k
+                m1 = m0.newMCMC(burn=1, stride=1, rotateParams=True)
+                k1s = inj.k
+                m1.MC_append(300)
+                k2 = inj.k
+                m2 = m1.newMCMC(burn=1, stride=1, noCorrelations=False, doBlock=False)
+                k2s = inj.k
+                m2.MC_append(200)
+            for tag, m in (("c0", m0), ("c1", m1), ("c2", m2)):
+                g["chain__%s_samples" % tag] = m.samples.copy()
+                g["chain__%s_lnPr" % tag] = m.lnPr.copy()
+                g["chain__%s_accepted" % tag] = m.accepted.astype(bool)
+                g["chain__%s_naccept" % tag] = m.naccept
+                g["chain__%s_sigmas" % tag] = np.asarray(m.prop.sigmas, float)
+                g["chain__%s_sqrt" % tag] = (np.asarray(m.prop.sqrtMatrix, float)
+                                              if m.prop.sqrtMatrix is not None else np.zeros((0, 0)))
+            g["chain__accept0"] = m0.accept.copy()
+            g["chain__accept1"] = m1.accept.copy()
+            g["chain__k"] = np.array([k_start, k1, k1s, k2, k2s, inj.k])
+            g["chain__normals"] = inj.normals[:inj.k].copy()
+            g["chain__uniforms"] = inj.uniforms[:inj.k].copy()
+            g["chain__start"] = truth.copy()
+            print("cl chain: naccept", m0.naccept, m1.naccept, m2.naccept, "draw rows", inj.k)
+    np.savez_compressed(os.path.join(OUT, "cl_g5.npz"), **g)
+    print("wrote cl_g5.npz")
+
+
+# ---------------------------------------------------------------------------------------------
+# G6: BeamFit 2-D Gaussian beam (SURVEY row A10)
+# ---------------------------------------------------------------------------------------------
+def golden_beam(R):
+    OM = R["BeamFit.OffsetNormalizedBeamModel"]
+    NL = R["BeamFit.NormalizedBeamLikelihood"]
+    BD = R["BeamFit.BeamData"]
+    MC, Prop = R["MCMC"], R["Proposal"]
+    import contextlib
+    import io
+    sha = ref_tree_sha()
+    rng = np.random.default_rng(606)
+    mod = OM.OffsetNormalizedBeamModel
+    half = 20.0
+    # class-level prior state, as ProcessBeamData.setup_sampler leaves it (:149-151, :215-216)
+    mod.centerMin, mod.centerMax = (-half, -half), (half, half)
+    mod.sigMin, mod.sigMax = 3, 8
+    mod.paramBlocks = [0, 1, 2, 3, 4, 5, 6]
+    mod.nBlock = 7
+    g = dict(ref_sha=sha, centerMin=np.array(mod.centerMin), centerMax=np.array(mod.centerMax),
+             sigMin=float(mod.sigMin), sigMax=float(mod.sigMax))
+
+    def make_map(n, per_pixel_sigma=False, scattered=False):
+        if scattered:
+            x = rng.uniform(-half, half, n * n)
+            y = rng.uniform(-half, half, n * n)
+        else:
+            gg = np.linspace(-half, half, n)
+            xx, yy = np.meshgrid(gg, gg)
+            x, y = xx.ravel(), yy.ravel()
+        th = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(3, 8), rng.uniform(3, 8),
+                       rng.uniform(0, math.pi), 10.0, 0.01, 1.0, 0.0])
+        with np.errstate(all="ignore"):
+            m = mod(*mod.package(th)).atxy(x, y)
+        sig = 0.1 * (1 + 0.5 * rng.uniform(size=n * n)) if per_pixel_sigma else 0.1
+        d = m + sig * rng.standard_normal(n * n)
+        return x, y, d, sig, th
+
+    NT = 16
+    maps = [("m64a", 64, False, False), ("m64b", 64, True, False), ("m48s", 48, False, True),
+            ("m256", 256, False, False)]
+    for name, n, pps, scat in maps:
+        x, y, d, sig, truth = make_map(n, pps, scat)
+        data = BD.BeamData(x, y, d.copy(), sig)
+        like = NL.NormalizedBeamLikelihood(data=data, model=mod)
+        th = truth[None, :] * (1 + 0.05 * rng.standard_normal((NT, 9)))
+        th[:, 7] = rng.uniform(0.7, 1.0, NT)          # tilted planes
+        th[:, 8] = rng.uniform(-1.0, 7.5, NT)         # phi outside [0, 2pi): package reduces it
+        th[:, 6] = 0.01 * rng.standard_normal(NT)
+        th[0] = truth                                 # mu == 1: planexy returns 0 (:150)
+        th[1, 4] = -0.4                               # negative angle -> mod pi
+        th[2, 4] = 4.0
+        th[3, 5] = -1.0                               # amplitude <= 0: prior 0
+        th[4, 7] = -0.9                               # |mu|
+        th[5, 0] = 25.0                               # centre outside the box
+        th[6, 2] = 2.0                                # sigma below sigMin
+        th[7, 3] = 9.5                                # sigma above sigMax
+        th[8, 7] = 1.3                                # mu > 1: prior 0, sqrt(negative) -> NaN model
+        th[9, 7] = 0.0                                # mu == 0: division by zero -> inf
+        lnl = np.empty(NT); pri = np.empty(NT); pk = np.empty((NT, 9))
+        mv = np.empty((NT, 5))
+        pix = np.array([0, n + 3, (n * n) // 2, n * n - n - 2, n * n - 1])
+        with np.errstate(all="ignore"):
+            for t in range(NT):
+                p = mod.package(th[t])
+                pk[t] = mod.unpackage(p)
+                pri[t] = mod.prior(*p)
+                lnl[t] = like.lnLike(p)
+                mv[t] = like.model_vals[0][pix]
+            dcopy = BD.BeamData(x, y, d.copy(), sig)
+            st = dcopy.stats(sigcut=0.0)
+        pre = name + "__"
+        g[pre + "x"], g[pre + "y"], g[pre + "d"] = x, y, d
+        g[pre + "sig"] = np.atleast_1d(np.asarray(sig, float))
+        g[pre + "truth"], g[pre + "theta"] = truth, th
+        g[pre + "lnl"], g[pre + "prior"], g[pre + "package"] = lnl, pri, pk
+        g[pre + "pix"], g[pre + "model_vals"] = pix, mv
+        g[pre + "stats"] = np.array(st, float)
+        print("beam %-5s lnL(truth)=%r" % (name, lnl[0]))
+        if name == "m64a":
+            r = np.random.default_rng(31)
+            nrows = 1500
+            inj = Injector(r.standard_normal((nrows, 9)), r.uniform(size=nrows))
+            Prop.normal = inj.normal
+            MC.uniform = inj.uniform
+            sigmas = np.array([4.0, 4.0, 4.0, 4.0, 0.6, 2 * (d.max() - d.min()), 0.3, 0, 0]) * 0.05
+            start = truth * np.array([1.05, 0.9, 1.1, 0.95, 1.0, 1.1, 1.0, 1.0, 1.0])
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                m0 = MC.MCMC(like, startProposal=mod.package(sigmas), startParams=mod.package(start),
+                             doBlock=True)
+                k_start = inj.k
+                m0.MC_append(500)
+                k1 = inj.k
+                m1 = m0.newMCMC(burn=1, stride=1, noCorrelations=False)
+                k1s = inj.k
+                m1.MC_append(300)
+            for tag, m in (("c0", m0), ("c1", m1)):
+                g["chain__%s_samples" % tag] = m.samples.copy()
+                g["chain__%s_lnPr" % tag] = m.lnPr.copy()
+                g["chain__%s_accepted" % tag] = m.accepted.astype(bool)
+                g["chain__%s_naccept" % tag] = m.naccept
+                g["chain__%s_accept" % tag] = m.accept.copy()
+                g["chain__%s_sigmas" % tag] = np.asarray(m.prop.sigmas, float)
+                g["chain__%s_sqrt" % tag] = (np.asarray(m.prop.sqrtMatrix, float)
+                                              if m.prop.sqrtMatrix is not None else np.zeros((0, 0)))
+            g["chain__k"] = np.array([k_start, k1, k1s, inj.k])
+            g["chain__normals"] = inj.normals[:inj.k].copy()
+            g["chain__uniforms"] = inj.uniforms[:inj.k].copy()
+            g["chain__start"], g["chain__sigmas"] = start, sigmas
+            print("beam chain: naccept", m0.naccept, m1.naccept, "accept", m0.accept, m1.accept)
+    np.savez_compressed(os.path.join(OUT, "beam_g6.npz"), **g)
+    print("wrote beam_g6.npz")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["sed", "cl", "beam"]
+    R = load_reference()
+    if "sed" in which:
+        golden_sed(R)
+    if "cl" in which:
+        golden_cl(R)
+    if "beam" in which:
+        golden_beam(R)
 
 
 if __name__ == "__main__":
