@@ -174,6 +174,63 @@ int mi355_rng_dump(mi355_ctx* ctx, int64_t step0, int64_t nsteps, int64_t N, int
 int mi355_math_probe(mi355_ctx* ctx, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* c, double* out);
 
+/* ---- binnedCl / ClData band-power likelihood: MCMC/binnedCl, MCMC/ClData ----------------- */
+/* One data set = the attributes of a ClData_CosmoMC object (ClData_CosmoMC.py:85-195 fills them
+ * from a .dataset file; the Python mirror class hands them over as arrays).  All host pointers. */
+typedef struct {
+  int32_t num_points;          /* bands nb                                        :94            */
+  int32_t win_len;             /* last dimension of window                        :198-258       */
+  const double* obs;           /* [nb]  ln(C+x) where has_xfactor, else C         :377-398       */
+  const double* N_inv;         /* [nb,nb] inverse covariance, or NULL: has_corr_errors False     */
+  const double* var;           /* [nb] variances, used when N_inv is NULL         :412,420       */
+  const double* xfactors;      /* [nb] or NULL (has_xfactors False)                              */
+  const uint8_t* has_xfactor;  /* [nb] or NULL                                                   */
+  const double* window;        /* [nb, 3, win_len]  TT, TE, EE windows            :422-446       */
+  const int32_t* win_min;      /* [nb]                                                           */
+  const int32_t* win_max;      /* [nb] inclusive; may exceed the spectrum length  :436           */
+  double calib_uncertainty;    /*                                                 :282,299,337   */
+  const double* beam_err;      /* [nb] or NULL (beam_uncertain False)             :293,334       */
+  int32_t has_pol;             /*                                                 :439           */
+  const uint8_t* inc_pol;      /* [nb] or NULL                                                   */
+} mi355_cl_dataset;
+
+/* like.data = [ClData, ...]: replaces any data sets loaded before. */
+int mi355_cl_load(mi355_ctx* ctx, int32_t ndata, const mi355_cl_dataset* data);
+/* binnedClModel.setBinning(bins, shapefun) (binnedClModel.py:145-252): nCl <= 3 spectra (TT, TE,
+ * EE), nbins[iCl] bins each, bins host [sum nbins, 2] inclusive (lmin, lmax) in parameter order,
+ * shapefun host [nCl, lmax+1] = D_l shape with lmax the largest binned multipole (the caller
+ * truncates).  Bins of one spectrum must not overlap.  Builds the band-power
+ * matrices K, BP0 of every loaded data set on the device. */
+int mi355_cl_set_binning(mi355_ctx* ctx, int32_t nCl, const int32_t* nbins, const int32_t* bins,
+                         const double* shapefun, int32_t lmax);
+int32_t mi355_cl_nparam(mi355_ctx* ctx);
+/* binnedClLikelihood.lnLike(q) (binnedClLikelihood.py:26-32 -> ClData_CosmoMC.calcLnLike :267-315)
+ * summed over the loaded data sets, for n parameter vectors: q host [n, npar] -> lnL host [n]. */
+int mi355_cl_lnlike(mi355_ctx* ctx, int64_t n, const double* q, double* lnL);
+/* Same on device memory: q_dev parameter-major [npar, n], lnL_dev [n]; asynchronous. */
+int mi355_cl_lnlike_dev_async(mi355_ctx* ctx, int64_t n, const double* q_dev, double* lnL_dev);
+/* binnedClModel.prior(*q) (:125-132): host [n, npar] -> prior [n]. */
+int mi355_cl_prior(mi355_ctx* ctx, int64_t n, const double* q, double* prior);
+/* binnedClModel(q)() (:62-86): host q [n, npar] -> Cl [n, 3, lmax+1]. */
+int mi355_cl_model(mi355_ctx* ctx, int64_t n, const double* q, double* Cl);
+/* Band powers of data set idata: from bin amplitudes (what==0, in host [n, npar], through K) or
+ * from explicit spectra as getWinBandpower does (what==1, in host [n, rows, L], rows 1 or 3;
+ * :422-446) -> bp host [n, nb]. */
+int mi355_cl_bandpowers(mi355_ctx* ctx, int32_t idata, int32_t what, int64_t n, const double* in,
+                        int32_t rows, int32_t L, double* bp);
+/* Methods of ClData_CosmoMC on explicit vectors, data set idata, host [n, nb] in:
+ *  op 0: getdelta(BP)   -> out [n, nb]   :377-398
+ *  op 1: getlinform(v)  -> out [n, nb]   :407-412
+ *  op 2: getquadform(v) -> out [n]       :415-420
+ *  op 3: getchisq(BP)   -> out [n]       :400-405
+ *  op 4: calcLnLike from band powers (marginalisations included) -> out [n] = -ln L   :267-315 */
+int mi355_cl_data_op(mi355_ctx* ctx, int32_t idata, int32_t op, int64_t n, const double* in,
+                     double* out);
+/* ClData_CosmoMC.calcLnLike(Cl) (:267-315) for explicit spectra: Cl host [n, rows, L] -> out [n]
+ * (= MINUS ln L, as the reference returns it). */
+int mi355_cl_calc_lnlike(mi355_ctx* ctx, int32_t idata, int64_t n, const double* Cl, int32_t rows,
+                         int32_t L, double* out);
+
 /* ---- Gelman-Rubin: MCMC/convergence.py:58-87 -------------------------------------------- */
 /* Per-source partial sums over this context's C chains, for an all-reduce across GPUs that
  * hold different chains of the same sources (chain-sharded layout).  dev buffers:

@@ -24,6 +24,15 @@ class SedModel(C.Structure):
                 ("nu_rescale", C.c_double)]
 
 
+class ClDataset(C.Structure):
+    """mirror of mi355_cl_dataset"""
+    _fields_ = [("num_points", C.c_int32), ("win_len", C.c_int32), ("obs", c_double_p),
+                ("N_inv", c_double_p), ("var", c_double_p), ("xfactors", c_double_p),
+                ("has_xfactor", c_uint8_p), ("window", c_double_p), ("win_min", c_int32_p),
+                ("win_max", c_int32_p), ("calib_uncertainty", C.c_double), ("beam_err", c_double_p),
+                ("has_pol", C.c_int32), ("inc_pol", c_uint8_p)]
+
+
 # name -> (restype, argtypes); every symbol include/mi355mcmc.h declares
 SIGNATURES = {
     "mi355_init": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -61,6 +70,18 @@ SIGNATURES = {
                                        C.c_int64, c_double_p, C.c_int64, c_double_p]),
     "mi355_math_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p,
                                    c_double_p]),
+    "mi355_cl_load": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(ClDataset)]),
+    "mi355_cl_set_binning": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, C.c_int32]),
+    "mi355_cl_nparam": (C.c_int32, [C.c_void_p]),
+    "mi355_cl_lnlike": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p]),
+    "mi355_cl_lnlike_dev_async": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mi355_cl_prior": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p]),
+    "mi355_cl_model": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p]),
+    "mi355_cl_bandpowers": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_double_p,
+                                      C.c_int32, C.c_int32, c_double_p]),
+    "mi355_cl_data_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_double_p, c_double_p]),
+    "mi355_cl_calc_lnlike": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_double_p, C.c_int32,
+                                       C.c_int32, c_double_p]),
     "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mi355_gelman_rubin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),

@@ -1,0 +1,459 @@
+// HIP kernels of the binned-C_l band-power likelihood.
+//
+// Reference arithmetic: MCMC/binnedCl/binnedClModel.py:62-86 (q_b -> C_l), :125-132 (prior);
+// MCMC/ClData/ClData_CosmoMC.py:267-315 (calcLnLike), :317-372 (11x11 numeric calibration/beam
+// marginalisation), :377-398 (offset-lognormal delta), :407-420 (linear / quadratic forms),
+// :422-446 (window band powers).
+//
+// Device formulation.  The band powers are linear in the bin amplitudes, BP = q.K + BP0 with K
+// built once per (binning, dataset) by k_cl_build_K, so a likelihood evaluation is
+//   k_cl_bandpower : BP[band][chain]                                  (small GEMM, VALU)
+//   k_cl_form      : rows = (chain x marginalisation point); delta rows generated into LDS,
+//                    Y = delta . N^-1 on v_mfma_f64_16x16x4_f64, chi2 = rowsum(Y * delta)
+//   k_cl_combine   : log-sum-exp over the 11 (x11) grid / analytic marginalisation, -chi2/2.
+#pragma once
+#include "common.hpp"
+
+namespace mi355 {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kClHalfSteps = 5;          // ClData_CosmoMC.py:40
+constexpr int kClGrid = 2 * kClHalfSteps + 1;
+
+enum ClFormMode : int { CL_ROWS_MARGE = 0, CL_ROWS_TRIPLE = 1, CL_ROWS_RAW = 2 };
+
+struct ClFormArgs {
+  const double* bp;        // [nbp][n]  band powers, band-major (RAW: the row vectors themselves)
+  int64_t n;               // chains
+  int nb, nbp;             // bands, padded to a multiple of 16
+  const double* obs;       // [nbp]
+  const double* xf;        // [nbp] x-factors (0 where none)
+  const uint8_t* hasx;     // [nbp]
+  const double* beam_err;  // [nbp] (zeros when !beam_uncertain)
+  const double* ninv;      // [nbp][nbp] zero padded (full covariance) ...
+  const double* var;       // ... or [nbp] variances (uncorrelated errors)
+  int has_x;               // dataset has_xfactors
+  int beam_uncertain;
+  double calib;            // calib_uncertainty
+  int mode;                // ClFormMode
+  int ncal, nbeam;         // marginalisation grid (1 or 11 each); rows per chain = ncal*nbeam
+  int64_t rows;            // total rows = n * rows_per_chain (3 per chain in TRIPLE mode)
+  double* out;             // MARGE: chisq[rows]; TRIPLE: G[n][9]
+};
+
+// Value of element `k` (band) of row `grow`: the vector the quadratic form is taken of.
+__device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int64_t grow, int k) {
+  if (grow >= a.rows || k >= a.nb) return 0.0;
+  if (a.mode == CL_ROWS_RAW) return a.bp[static_cast<int64_t>(k) * a.n + grow];   // getquadform(vec)
+  if (a.mode == CL_ROWS_TRIPLE) {
+    const int64_t c = grow / 3;
+    const int t = static_cast<int>(grow - 3 * c);
+    const double bp = a.bp[static_cast<int64_t>(k) * a.n + c];
+    if (t == 0) return a.obs[k] - bp;                    // getdelta without x-factors, :396
+    if (t == 1) return bp;                               // :289
+    return a.beam_uncertain ? a.beam_err[k] * bp : 0.0;  // :293
+  }
+  const int npc = a.ncal * a.nbeam;
+  const int64_t c = grow / npc;
+  const int m = static_cast<int>(grow - c * npc);
+  double v = a.bp[static_cast<int64_t>(k) * a.n + c];
+  if (a.nbeam > 1) {                                     // :333-334
+    const int ib = m / a.ncal - kClHalfSteps;
+    v *= 1.0 + a.beam_err[k] * ib * 3 / kClHalfSteps;
+  }
+  if (a.ncal > 1) {                                      // :337-338
+    const int ic = m % a.ncal - kClHalfSteps;
+    const double calib = 1.0 + a.calib * ic * 3 / kClHalfSteps;
+    v = calib * v;
+  }
+  if (a.has_x && a.hasx[k]) {                            // :383-392
+    double zth = v + a.xf[k];
+    if (zth <= 0.0) zth = 0.0;                           // forces -inf rather than NaN, :389
+    return a.obs[k] - log(zth);
+  }
+  return a.obs[k] - v;
+}
+
+// Full-covariance forms on the FP64 matrix cores.  256 threads = 4 waves; the block owns
+// TR = 16*RT rows (all waves share them) and every wave owns the column tiles ct = w, w+4, ...
+// of Y = V.N^-1.  V is staged band-major in LDS (vt[k][TR]); N^-1 fragments come straight from
+// L2 (the matrix is shared by every block).  MFMA operand maps (cdna_hip_programming.md sect. 3):
+// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4*reg.
+template <int RT>
+__global__ __launch_bounds__(256) void k_cl_form(ClFormArgs a) {
+  constexpr int TR = 16 * RT;
+  constexpr int CG = 4;                       // column tiles per wave per pass
+  extern __shared__ double smem[];
+  double* vt = smem;                          // [nbp][TR]
+  double* red = smem + static_cast<size_t>(a.nbp) * TR;   // [4][TR][3]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * rows_used;
+
+  for (int idx = tid; idx < a.nbp * TR; idx += 256) {
+    const int k = idx / TR, r = idx - k * TR;
+    vt[idx] = (r < rows_used) ? cl_row_value(a, row0 + r, k) : 0.0;
+  }
+  __syncthreads();
+
+  const int nct = a.nbp >> 4;
+  const int lk = lane >> 4, lc = lane & 15;
+  // per-lane partial row sums: MARGE uses [.][.][0] only
+  double part[RT][4][3];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[rt][i][0] = part[rt][i][1] = part[rt][i][2] = 0.0;
+
+  for (int ct0 = w; ct0 < nct; ct0 += 4 * CG) {
+    double4_t acc[RT][CG];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < CG; ++j) acc[rt][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    int ctj[CG];
+    bool live[CG];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      live[j] = ct0 + 4 * j < nct;
+      ctj[j] = live[j] ? ct0 + 4 * j : ct0;
+    }
+#pragma unroll 2
+    for (int k0 = 0; k0 < a.nbp; k0 += 4) {
+      double av[RT], bv[CG];
+      const double* vrow = vt + (k0 + lk) * TR + lc;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) av[rt] = vrow[rt * 16];
+      const double* nrow = a.ninv + static_cast<size_t>(k0 + lk) * a.nbp + lc;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) bv[j] = nrow[ctj[j] * 16];
+#pragma unroll
+      for (int j = 0; j < CG; ++j)
+        if (live[j]) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv[j], acc[rt][j], 0, 0, 0);
+        }
+    }
+    // epilogue: Y[row][col] * V[row'][col] summed over this wave's columns
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      if (!live[j]) continue;
+      const int col = ctj[j] * 16 + lc;
+      if (col >= a.nb) continue;               // padded columns: Y there is 0*V (or NaN)
+      const double* vcol = vt + col * TR;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = rt * 16 + lk + 4 * i;
+          const double y = acc[rt][j][i];
+          if (a.mode == CL_ROWS_TRIPLE) {
+            const int g3 = (row / 3) * 3;
+            if (row < rows_used) {
+              part[rt][i][0] = fma(y, vcol[g3 + 0], part[rt][i][0]);
+              part[rt][i][1] = fma(y, vcol[g3 + 1], part[rt][i][1]);
+              part[rt][i][2] = fma(y, vcol[g3 + 2], part[rt][i][2]);
+            }
+          } else {
+            part[rt][i][0] = fma(y, vcol[row], part[rt][i][0]);
+          }
+        }
+    }
+  }
+  // reduce over the 16 lanes that share (lane>>4), i.e. over columns
+  const int nt = (a.mode == CL_ROWS_TRIPLE) ? 3 : 1;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t >= nt) continue;
+        double v = part[rt][i][t];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        if (lc == 0) red[(w * TR + rt * 16 + lk + 4 * i) * 3 + t] = v;
+      }
+  __syncthreads();
+  for (int idx = tid; idx < rows_used * nt; idx += 256) {
+    const int r = idx / nt, t = idx - r * nt;
+    const int64_t grow = row0 + r;
+    if (grow >= a.rows) continue;
+    const double s = ((red[(0 * TR + r) * 3 + t] + red[(1 * TR + r) * 3 + t]) +
+                      red[(2 * TR + r) * 3 + t]) + red[(3 * TR + r) * 3 + t];
+    if (a.mode == CL_ROWS_TRIPLE) {
+      const int64_t c = grow / 3;
+      a.out[c * 9 + (grow - 3 * c) * 3 + t] = s;         // G[c][row type][t]
+    } else {
+      a.out[grow] = s;
+    }
+  }
+}
+
+// Uncorrelated errors (has_corr_errors False): sum(vec**2/var), vec/var (:412, :420).
+// One thread per row (MARGE) or per chain (TRIPLE), bands in ascending order like the
+// reference's builtin sum().
+__global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a.mode == CL_ROWS_TRIPLE) {
+    if (i >= a.n) return;
+    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < a.nb; ++k) {
+      double v[3];
+      for (int t = 0; t < 3; ++t) v[t] = cl_row_value(a, 3 * i + t, k);
+      const double var = a.var[k];
+      g[0] += v[0] * v[0] / var;                         // getquadform, :420
+      for (int t = 1; t < 3; ++t) {
+        const double lin = v[t] / var;                   // getlinform, :412
+        for (int u = 0; u < 3; ++u) g[t * 3 + u] += v[u] * lin;
+      }
+    }
+    for (int t = 0; t < 9; ++t) a.out[i * 9 + t] = g[t];
+  } else {
+    if (i >= a.rows) return;
+    double s = 0.0;
+    for (int k = 0; k < a.nb; ++k) {
+      const double v = cl_row_value(a, i, k);
+      s += v * v / a.var[k];
+    }
+    a.out[i] = s;
+  }
+}
+
+// ---- marginalisation and -ln L ------------------------------------------------------------
+struct ClCombineArgs {
+  const double* form;      // chisq[n*npc] or G[n][9]
+  int64_t n;
+  int mode, ncal, nbeam;
+  int beam_uncertain;
+  double calib;
+  const double* weights;   // [11] margeweights, :42-47
+  double margenorm;
+  double* lnl;             // [n]
+  int accumulate;          // 0: lnl = -neglnl, 1: lnl += -neglnl (sum over datasets)
+  double* neglnl;          // nullable [n]: calcLnLike's own return value
+};
+
+// -2 ln( sum_i w_i exp(-(c_i - min)/2) / norm ) + min over an 11-point grid, :340-354
+__device__ __forceinline__ double cl_marge11(const double* c, int stride, const double* w,
+                                             double norm) {
+  double mn = c[0];
+  for (int i = 1; i < kClGrid; ++i) {
+    const double v = c[i * stride];
+    if (v < mn) mn = v;                                  // Python min(): first smallest, NaN-blind
+  }
+  double s = 0.0;
+  for (int i = 0; i < kClGrid; ++i) s += w[i] * exp(-(c[i * stride] - mn) / 2);
+  return -2 * log(s / norm) + mn;
+}
+
+__global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= a.n) return;
+  double chisq;
+  if (a.mode == CL_ROWS_MARGE) {
+    const int npc = a.ncal * a.nbeam;
+    const double* f = a.form + c * npc;
+    if (npc == 1) {
+      chisq = f[0];
+    } else {
+      double cc[kClGrid];
+      for (int ib = 0; ib < a.nbeam; ++ib) {
+        if (a.ncal > 1) {
+          cc[ib] = cl_marge11(f + ib * a.ncal, 1, a.weights, a.margenorm);
+        } else {
+          // calib_uncertainty == 0: the 11 calibration points are the same number and the
+          // weighted mean of exp(0) is exactly 1 (same summation order as margenorm)
+          cc[ib] = f[ib];
+        }
+      }
+      chisq = (a.nbeam > 1) ? cl_marge11(cc, 1, a.weights, a.margenorm) : cc[0];
+    }
+  } else {                                               // analytic, :286-313
+    const double* g = a.form + c * 9;
+    chisq = g[0];
+    const double chi2op = g[3], chi2pp = g[4];
+    const double chi2od = g[6], chi2pd = g[7], chi2dd = g[8];
+    double denom = 1.0, wpp = 0.0;
+    bool touched = false;
+    if (a.calib > 1.0e-4) {
+      wpp = 1 / (chi2pp + 1 / (a.calib * a.calib));
+      chisq -= wpp * (chi2op * chi2op);
+      denom /= wpp * (a.calib * a.calib);
+      touched = true;
+    }
+    if (a.beam_uncertain) {
+      const double wdd = 1 / (chi2dd - wpp * (chi2pd * chi2pd) + 1);
+      const double t = chi2od - wpp * chi2op * chi2pd;
+      chisq -= wdd * (t * t);
+      denom /= wdd;
+      touched = true;
+    }
+    if (touched && denom != 1.0) chisq += log(denom);
+  }
+  const double neg = chisq / 2;                          // :315
+  if (a.neglnl) a.neglnl[c] = neg;
+  if (a.lnl) a.lnl[c] = a.accumulate ? a.lnl[c] + (-neg) : (0.0 + (-neg));
+}
+
+// ---- band powers ----------------------------------------------------------------------------
+// BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i]     (q parameter-major [npar][n])
+__global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int nb, int nbp,
+                                                      const double* __restrict__ q,
+                                                      const double* __restrict__ K,
+                                                      const double* __restrict__ bp0,
+                                                      double* __restrict__ bp) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (c >= n) return;
+  double s = 0.0;
+  if (i < nb) {
+    s = bp0[i];
+    for (int b = 0; b < npar; ++b) s = fma(q[static_cast<int64_t>(b) * n + c], K[b * nbp + i], s);
+  }
+  bp[static_cast<int64_t>(i) * n + c] = s;
+}
+
+struct ClBinning {
+  int nCl, npar, lmax;     // model lmax (largest binned multipole)
+  const double* shapefun;  // [nCl][lmax+1]
+  const int32_t* binof;    // [nCl][lmax+1] flat parameter index of the bin holding l, -1 if none
+};
+
+__device__ __forceinline__ double cl_ellnorm(int l) {     // binnedClModel.py:216-219
+  if (l == 0) return 0.0;
+  const double e = static_cast<double>(l);
+  return 2 * 3.141592653589793 / (e * (e + 1.0));
+}
+
+// K[b][i], BP0[i] of one dataset: one thread per band walks its window (set-up, runs once).
+__global__ void k_cl_build_K(ClBinning m, int nb, int nbp, int wl, const double* __restrict__ window,
+                             const int32_t* __restrict__ win_min, const int32_t* __restrict__ win_max,
+                             int has_pol, const uint8_t* __restrict__ inc_pol, double* K,
+                             double* bp0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const int lo = win_min[i];
+  int maxl = win_max[i] + 1;                              // :436
+  if (maxl > m.lmax + 1) maxl = m.lmax + 1;
+  if (maxl > wl) maxl = wl;
+  double z = 0.0;
+  const int ncl_used = (has_pol && inc_pol[i]) ? 3 : 1;   // :437-442
+  for (int iCl = 0; iCl < ncl_used && iCl < m.nCl; ++iCl)
+    for (int l = lo; l < maxl; ++l) {
+      const double t = m.shapefun[iCl * (m.lmax + 1) + l] * cl_ellnorm(l) *
+                       window[(static_cast<size_t>(i) * 3 + iCl) * wl + l];
+      const int b = m.binof[iCl * (m.lmax + 1) + l];
+      if (b < 0) z += t;
+      else K[b * nbp + i] += t;
+    }
+  bp0[i] = z;
+}
+
+// binnedClModel.__call__ (:62-86): Cl[c][iCl][l] = (shape * q_b) * ellnorm, rows >= nCl zero.
+__global__ __launch_bounds__(256) void k_cl_model(ClBinning m, int64_t n, const double* __restrict__ q
+                                                  /*[n][npar]*/, double* __restrict__ out /*[n][3][lmax+1]*/) {
+  const int L = m.lmax + 1;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * 3 * L) return;
+  const int l = static_cast<int>(e % L);
+  const int iCl = static_cast<int>((e / L) % 3);
+  const int64_t c = e / (3 * L);
+  double v = 0.0;
+  if (iCl < m.nCl) {
+    v = m.shapefun[iCl * L + l];
+    const int b = m.binof[iCl * L + l];
+    if (b >= 0) v *= q[c * m.npar + b];
+    v *= cl_ellnorm(l);
+  }
+  out[e] = v;
+}
+
+// getWinBandpower (:422-446) for explicit spectra: one wave per (chain, band).
+// Cl host layout [n][rows][L]; rows = 1 (TT only, ndim==1 in the reference) or 3.
+__global__ __launch_bounds__(256) void k_cl_bandpower_direct(
+    int64_t n, int rows, int L, const double* __restrict__ Cl, int nb, int wl,
+    const double* __restrict__ window, const int32_t* __restrict__ win_min,
+    const int32_t* __restrict__ win_max, int has_pol, const uint8_t* __restrict__ inc_pol,
+    double* __restrict__ bp /*[nbp][n]*/) {
+  const int64_t wv = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wv >= n * nb) return;
+  const int64_t c = wv / nb;
+  const int i = static_cast<int>(wv % nb);
+  const int lo = win_min[i];
+  int maxl = win_max[i] + 1;
+  if (maxl > L) maxl = L;
+  if (maxl > wl) maxl = wl;
+  const int ncl_used = (has_pol && inc_pol[i] && rows >= 3) ? 3 : 1;
+  double s = 0.0;
+  for (int iCl = 0; iCl < ncl_used; ++iCl)
+    for (int l = lo + lane; l < maxl; l += 64)
+      s = fma(Cl[(c * rows + iCl) * L + l], window[(static_cast<size_t>(i) * 3 + iCl) * wl + l], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) bp[static_cast<int64_t>(i) * n + c] = s;
+}
+
+// prior (:125-132, positive_corr): 0 if any auto-spectrum bin is negative
+__global__ void k_cl_prior(int64_t n, int npar, const int32_t* __restrict__ cltype,
+                           const double* __restrict__ q /*[n][npar]*/, double* __restrict__ prior) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double p = 1.0;
+  for (int b = 0; b < npar; ++b)
+    if (cltype[b] != 1 && q[c * npar + b] < 0) p = 0.0;
+  prior[c] = p;
+}
+
+// getdelta (:377-398) of explicit band-power vectors: BP host layout [n][nb] -> delta [n][nb]
+__global__ void k_cl_delta(int64_t n, int nb, const double* __restrict__ BP,
+                           const double* __restrict__ obs, const double* __restrict__ xf,
+                           const uint8_t* __restrict__ hasx, int has_x, double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * nb) return;
+  const int k = static_cast<int>(e % nb);
+  const double v = BP[e];
+  if (has_x && hasx[k]) {
+    double zth = v + xf[k];
+    if (zth <= 0.0) zth = 0.0;
+    out[e] = obs[k] - log(zth);
+  } else {
+    out[e] = obs[k] - v;
+  }
+}
+
+// getlinform (:407-412): out[c][i] = sum_k N^-1[i][k] vec[c][k]  (or vec/var)
+__global__ __launch_bounds__(256) void k_cl_linform(int64_t n, int nb, int nbp,
+                                                    const double* __restrict__ vec,
+                                                    const double* __restrict__ ninv,
+                                                    const double* __restrict__ var,
+                                                    double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * nb) return;
+  const int i = static_cast<int>(e % nb);
+  const int64_t c = e / nb;
+  if (!ninv) {
+    out[e] = vec[e] / var[i];
+    return;
+  }
+  double s = 0.0;
+  for (int k = 0; k < nb; ++k) s = fma(ninv[static_cast<size_t>(i) * nbp + k], vec[c * nb + k], s);
+  out[e] = s;
+}
+
+// [n][cols] -> [colsp][n] with zero padding rows
+__global__ void k_cl_to_bandmajor(int64_t n, int cols, int colsp, const double* __restrict__ in,
+                                  double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * colsp) return;
+  const int k = static_cast<int>(e / n);
+  const int64_t c = e % n;
+  out[e] = (k < cols) ? in[c * cols + k] : 0.0;
+}
+
+}  // namespace mi355

@@ -66,6 +66,15 @@ constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
 constexpr int kBandFields = 7;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, ln(base) hi, lo
 constexpr int kBlockThreads = 256;
 
+struct ClProblem;     // cl_api.hip
+struct BeamProblem;   // beam_api.hip
+struct GmhState;      // gmh_api.hip
+void cl_destroy(ClProblem*);
+void beam_destroy(BeamProblem*);
+void gmh_destroy(GmhState*);
+
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 struct SedConsts {
   double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
@@ -114,4 +123,9 @@ struct mi355_ctx {
 
   // --- scratch ------------------------------------------------------------------------
   mi355::DevBuf<double> scratch_a, scratch_b, scratch_c;
+
+  // --- other problem kinds (owned; each lives in its own translation unit) -----------------
+  mi355::ClProblem* cl = nullptr;       // binnedCl / ClData band-power likelihood
+  mi355::BeamProblem* beam = nullptr;   // BeamFit maps
+  mi355::GmhState* gmh = nullptr;       // step-wise Metropolis-Hastings over any problem kind
 };

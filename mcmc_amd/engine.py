@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Mi355Error, SedModel, c_double_p, c_int32_p, c_int64_p, c_uint8_p, check
+from ._lib import ClDataset, Mi355Error, SedModel, c_double_p, c_int32_p, c_int64_p, c_uint8_p, check
 
 MODEL_IDS = {"M1N": 0, "M1N_LOGA": 1, "M2N": 2, "M2N_LOGA": 3, "M1": 4, "M2": 5, "THICK": 6,
              "THICK_LOGA": 7}
@@ -243,6 +243,135 @@ class Engine:
         out = np.empty_like(a)
         check(self.lib.mi355_math_probe(self._h, int(fn), a.size, _dp(a), _dp(b), _dp(c), _dp(out)))
         return out
+
+    # ---- binnedCl / ClData -------------------------------------------------------------------
+    def cl_load(self, datasets):
+        """datasets: sequence of objects with the ClData_CosmoMC attributes (num_points, obs,
+        N_inv | var, xfactors, has_xfactor, window, win_min, win_max, calib_uncertainty,
+        beam_uncertain, beam_err, has_pol, inc_pol)."""
+        arr = (ClDataset * len(datasets))()
+        keep = []
+
+        def f64(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data_as(c_double_p)
+
+        def u8(a):
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+            keep.append(a)
+            return a.ctypes.data_as(c_uint8_p)
+
+        def i32(a):
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            keep.append(a)
+            return a.ctypes.data_as(c_int32_p)
+
+        self.cl_nb = []
+        for k, d in enumerate(datasets):
+            nb = int(d.num_points)
+            window = np.asarray(d.window, dtype=np.float64)
+            if window.ndim != 3 or window.shape[0] != nb or window.shape[1] != 3:
+                raise ValueError("window must be [num_points, 3, lmax+1]")
+            corr = bool(getattr(d, "has_corr_errors", getattr(d, "N_inv", None) is not None))
+            e = arr[k]
+            e.num_points, e.win_len = nb, window.shape[2]
+            e.obs = f64(np.asarray(d.obs).reshape(nb))
+            e.N_inv = f64(np.asarray(d.N_inv).reshape(nb, nb)) if corr else None
+            e.var = None if corr else f64(np.asarray(d.var).reshape(nb))
+            hasx = bool(getattr(d, "has_xfactors", False))
+            e.xfactors = f64(np.asarray(d.xfactors).reshape(nb)) if hasx else None
+            e.has_xfactor = u8(np.asarray(d.has_xfactor).reshape(nb)) if hasx else None
+            e.window = f64(window)
+            e.win_min, e.win_max = i32(d.win_min), i32(d.win_max)
+            e.calib_uncertainty = float(getattr(d, "calib_uncertainty", 0.0))
+            beam = bool(getattr(d, "beam_uncertain", False))
+            e.beam_err = f64(np.broadcast_to(np.asarray(d.beam_err, np.float64), (nb,))) if beam else None
+            pol = bool(getattr(d, "has_pol", False))
+            e.has_pol = int(pol)
+            e.inc_pol = u8(np.asarray(d.inc_pol).reshape(nb)) if pol else None
+            self.cl_nb.append(nb)
+        check(self.lib.mi355_cl_load(self._h, len(datasets), arr))
+        self.cl_npar = 0
+
+    def cl_set_binning(self, bins, shapefun):
+        """bins: per spectrum [nbin, 2] inclusive ranges; shapefun [nCl, lmax+1]."""
+        bins = [np.asarray(b, dtype=np.int32).reshape(-1, 2) for b in bins]
+        nbins = np.array([len(b) for b in bins], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(bins), dtype=np.int32)
+        lmax = int(flat.max())
+        shapefun = _f64(np.atleast_2d(shapefun))
+        if shapefun.shape != (len(bins), lmax + 1):
+            raise ValueError("shapefun must be [nCl=%d, lmax+1=%d] (truncate it to the largest binned "
+                             "multipole), got %s" % (len(bins), lmax + 1, shapefun.shape))
+        check(self.lib.mi355_cl_set_binning(self._h, len(bins), nbins.ctypes.data_as(c_int32_p),
+                                            flat.ctypes.data_as(c_int32_p), _dp(shapefun), lmax))
+        self.cl_npar = int(self.lib.mi355_cl_nparam(self._h))
+        self.cl_lmax = lmax
+
+    def cl_lnlike(self, q):
+        q = _f64(q)
+        single = q.ndim == 1
+        q2 = q.reshape(-1, self.cl_npar)
+        out = np.empty(q2.shape[0])
+        check(self.lib.mi355_cl_lnlike(self._h, q2.shape[0], _dp(q2), _dp(out)))
+        return float(out[0]) if single else out
+
+    def cl_lnlike_dev(self, q_ptr, lnl_ptr, n):
+        check(self.lib.mi355_cl_lnlike_dev_async(self._h, int(n), C.c_void_p(q_ptr), C.c_void_p(lnl_ptr)))
+
+    def cl_prior(self, q):
+        q = _f64(q)
+        single = q.ndim == 1
+        q2 = q.reshape(-1, self.cl_npar)
+        out = np.empty(q2.shape[0])
+        check(self.lib.mi355_cl_prior(self._h, q2.shape[0], _dp(q2), _dp(out)))
+        return out[0] if single else out
+
+    def cl_model(self, q):
+        q = _f64(q)
+        single = q.ndim == 1
+        q2 = q.reshape(-1, self.cl_npar)
+        out = np.empty((q2.shape[0], 3, self.cl_lmax + 1))
+        check(self.lib.mi355_cl_model(self._h, q2.shape[0], _dp(q2), _dp(out)))
+        return out[0] if single else out
+
+    def cl_bandpowers(self, idata, q=None, Cl=None):
+        nb = self.cl_nb[idata]
+        if q is not None:
+            a = _f64(q).reshape(-1, self.cl_npar)
+            what, rows, L = 0, 0, 0
+        else:
+            a = _f64(Cl)
+            if a.ndim == 1:
+                a = a[None, None, :]
+            elif a.ndim == 2:
+                a = a[None]
+            what, rows, L = 1, a.shape[1], a.shape[2]
+        out = np.empty((a.shape[0], nb))
+        check(self.lib.mi355_cl_bandpowers(self._h, int(idata), what, a.shape[0], _dp(a), rows, L, _dp(out)))
+        return out
+
+    def cl_data_op(self, idata, op, vec):
+        nb = self.cl_nb[idata]
+        v = _f64(vec)
+        single = v.ndim == 1
+        v2 = v.reshape(-1, nb)
+        out = np.empty(v2.shape if op in (0, 1) else v2.shape[0])
+        check(self.lib.mi355_cl_data_op(self._h, int(idata), int(op), v2.shape[0], _dp(v2), _dp(out)))
+        return out[0] if single else out
+
+    def cl_calc_lnlike(self, idata, Cl):
+        a = _f64(Cl)
+        single = a.ndim <= 2
+        if a.ndim == 1:
+            a = a[None, None, :]
+        elif a.ndim == 2:
+            a = a[None]
+        out = np.empty(a.shape[0])
+        check(self.lib.mi355_cl_calc_lnlike(self._h, int(idata), a.shape[0], _dp(a), a.shape[1],
+                                            a.shape[2], _dp(out)))
+        return float(out[0]) if single else out
 
     # ---- Gelman-Rubin ----------------------------------------------------------------------
     def rhat(self):
