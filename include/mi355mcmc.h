@@ -231,6 +231,46 @@ int mi355_cl_data_op(mi355_ctx* ctx, int32_t idata, int32_t op, int64_t n, const
 int mi355_cl_calc_lnlike(mi355_ctx* ctx, int32_t idata, int64_t n, const double* Cl, int32_t rows,
                          int32_t L, double* out);
 
+/* ---- BeamFit: MCMC/BeamFit ---------------------------------------------------------------- */
+/* Class-level prior state of GaussianBeamModel2D (BeamModel.py:41-43) as
+ * ProcessBeamData.setup_sampler sets it (:149-151); a has_* flag of 0 means "None". */
+typedef struct {
+  double center_min[2], center_max[2];
+  double sig_min, sig_max;
+  int32_t has_center, has_sig_min, has_sig_max;
+} mi355_beam_prior;
+
+/* M maps of npix pixels each (BeamData, BeamData.py:11-29 / GaussianData.py:13-28).
+ *  x, y : host [npix] shared by all maps (xy_per_map=0) or [M, npix] (=1)
+ *  d    : host [M, npix]
+ *  sig  : host [1] (sig_kind 0), [M] (1) or [M, npix] (2)
+ * Flat parameter vector (OffsetNormalizedBeamModel.unpackage, :123-127):
+ *  (x, y, sigma_1, sigma_2, angle, amplitude, offset, mu, phi). */
+int mi355_beam_load(mi355_ctx* ctx, int64_t M, int64_t npix, const double* x, const double* y,
+                    int32_t xy_per_map, const double* d, const double* sig, int32_t sig_kind,
+                    const mi355_beam_prior* prior);
+/* NormalizedBeamLikelihood.lnLike(package(theta)) (NormalizedBeamLikelihood.py:9-16 ->
+ * OffsetNormalizedBeamModel.at :78-82 -> gauss2d BeamModel.py:288-290 -> GaussianData.chi2) for
+ * maps [m0, m0+nm) x C parameter vectors each: theta host [nm, C, 9] -> lnL host [nm, C]. */
+int mi355_beam_lnlike(mi355_ctx* ctx, int64_t m0, int64_t nm, int32_t C, const double* theta,
+                      double* lnL);
+/* Same on device memory: theta_dev parameter-major [9, nm*C], lnL_dev [nm*C]; asynchronous. */
+int mi355_beam_lnlike_dev_async(mi355_ctx* ctx, int64_t m0, int64_t nm, int32_t C,
+                                const double* theta_dev, double* lnL_dev);
+/* model.prior(*package(theta)) (OffsetNormalizedBeamModel.py:93-101, BeamModel.py:165-187) and
+ * unpackage(package(theta)) (:123-133) for n flat vectors: host [n,9] -> prior [n], packaged [n,9]
+ * (either nullable). */
+int mi355_beam_prior_package(mi355_ctx* ctx, int64_t n, const double* theta, double* prior,
+                             double* packaged);
+/* model(*package(theta)).atxy(x, y) (:84-88): theta host [n,9], x, y host [npts] -> out [n, npts].
+ * Needs no maps. */
+int mi355_beam_model(mi355_ctx* ctx, int64_t n, const double* theta, int64_t npts, const double* x,
+                     const double* y, double* out);
+/* BeamData.stats(sigcut, do_abs) of map m (BeamData.py:35-71): out host [4] = <x>, <y>, var x,
+ * var y weighted by the mean-subtracted data (has_sigcut=0 means sigcut=None). */
+int mi355_beam_stats(mi355_ctx* ctx, int64_t m, int32_t has_sigcut, double sigcut, int32_t do_abs,
+                     double* out);
+
 /* ---- Gelman-Rubin: MCMC/convergence.py:58-87 -------------------------------------------- */
 /* Per-source partial sums over this context's C chains, for an all-reduce across GPUs that
  * hold different chains of the same sources (chain-sharded layout).  dev buffers:

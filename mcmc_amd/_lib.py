@@ -33,6 +33,13 @@ class ClDataset(C.Structure):
                 ("has_pol", C.c_int32), ("inc_pol", c_uint8_p)]
 
 
+class BeamPrior(C.Structure):
+    """mirror of mi355_beam_prior"""
+    _fields_ = [("center_min", C.c_double * 2), ("center_max", C.c_double * 2),
+                ("sig_min", C.c_double), ("sig_max", C.c_double), ("has_center", C.c_int32),
+                ("has_sig_min", C.c_int32), ("has_sig_max", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/mi355mcmc.h declares
 SIGNATURES = {
     "mi355_init": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -82,6 +89,15 @@ SIGNATURES = {
     "mi355_cl_data_op": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_double_p, c_double_p]),
     "mi355_cl_calc_lnlike": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_double_p, C.c_int32,
                                        C.c_int32, c_double_p]),
+    "mi355_beam_load": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p, c_double_p, C.c_int32,
+                                  c_double_p, c_double_p, C.c_int32, C.POINTER(BeamPrior)]),
+    "mi355_beam_lnlike": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p]),
+    "mi355_beam_lnlike_dev_async": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                              C.c_void_p]),
+    "mi355_beam_prior_package": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    "mi355_beam_model": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_int64, c_double_p, c_double_p,
+                                   c_double_p]),
+    "mi355_beam_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, c_double_p]),
     "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mi355_gelman_rubin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),

@@ -224,6 +224,7 @@ void mi355_free(mi355_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   cl_destroy(c->cl);
+  beam_destroy(c->beam);
   delete c;
 }
 

@@ -1,0 +1,213 @@
+// C ABI of the BeamFit path (include/mi355mcmc.h, "BeamFit" block).
+#include <cmath>
+#include <memory>
+
+#include "beam_kernels.hpp"
+
+namespace mi355 {
+
+struct BeamProblem {
+  int64_t M = 0, npix = 0;
+  int xy_per_map = 0, sig_kind = 0;
+  BeamPriorBox box{};
+  DevBuf<double> x, y, d, w, sig;
+  DevBuf<double> theta_in, theta_pm, partial, lnl, tmp;
+};
+
+void beam_destroy(BeamProblem* p) { delete p; }
+
+static int beam_ready(mi355_ctx* c, const char* who) {
+  MI355_REQUIRE(c && c->beam && c->beam->M > 0, "%s: no beam maps loaded (call mi355_beam_load)", who);
+  return 0;
+}
+
+// [n][9] -> [9][n]
+__global__ void k_beam_to_pm(int64_t n, const double* __restrict__ in, double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n * kBeamP) return;
+  const int i = static_cast<int>(e / n);
+  const int64_t k = e % n;
+  out[e] = in[k * kBeamP + i];
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_beam_load(mi355_ctx* c, int64_t M, int64_t npix, const double* x, const double* y,
+                    int32_t xy_per_map, const double* d, const double* sig, int32_t sig_kind,
+                    const mi355_beam_prior* prior) {
+  MI355_REQUIRE(c && x && y && d && sig && prior, "mi355_beam_load: null argument");
+  MI355_REQUIRE(M > 0 && npix > 0, "mi355_beam_load: empty input (M=%lld, npix=%lld)",
+                static_cast<long long>(M), static_cast<long long>(npix));
+  MI355_REQUIRE(sig_kind >= 0 && sig_kind <= 2, "mi355_beam_load: sig_kind %d", sig_kind);
+  MI355_HIP(hipSetDevice(c->device));
+  auto p = std::make_unique<BeamProblem>();
+  p->M = M;
+  p->npix = npix;
+  p->xy_per_map = xy_per_map ? 1 : 0;
+  p->sig_kind = sig_kind;
+  p->box.cmin[0] = prior->center_min[0];
+  p->box.cmin[1] = prior->center_min[1];
+  p->box.cmax[0] = prior->center_max[0];
+  p->box.cmax[1] = prior->center_max[1];
+  p->box.sig_min = prior->sig_min;
+  p->box.sig_max = prior->sig_max;
+  p->box.has_center = prior->has_center;
+  p->box.has_sig_min = prior->has_sig_min;
+  p->box.has_sig_max = prior->has_sig_max;
+  const size_t nxy = static_cast<size_t>(xy_per_map ? M : 1) * npix;
+  const size_t nd = static_cast<size_t>(M) * npix;
+  const size_t ns = sig_kind == 2 ? nd : (sig_kind == 1 ? static_cast<size_t>(M) : 1);
+  if (p->x.alloc(nxy) || p->y.alloc(nxy) || p->d.alloc(nd) || p->w.alloc(ns) || p->sig.alloc(ns))
+    return -2;
+  std::vector<double> w(ns);
+  for (size_t i = 0; i < ns; ++i) {
+    const double s2 = sig[i] * sig[i];                 // GaussianData.py:19
+    w[i] = 1.0 / s2;
+  }
+  MI355_HIP(hipMemcpyAsync(p->x.p, x, nxy * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(p->y.p, y, nxy * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(p->d.p, d, nd * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(p->w.p, w.data(), ns * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(p->sig.p, sig, ns * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  beam_destroy(c->beam);
+  c->beam = p.release();
+  return 0;
+}
+
+int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
+                                const double* theta_dev, double* lnL_dev) {
+  if (beam_ready(c, "mi355_beam_lnlike")) return -1;
+  BeamProblem* p = c->beam;
+  MI355_REQUIRE(theta_dev && lnL_dev, "mi355_beam_lnlike: null buffer");
+  MI355_REQUIRE(m0 >= 0 && nm > 0 && m0 + nm <= p->M, "map range [%lld,%lld) outside [0,%lld)",
+                static_cast<long long>(m0), static_cast<long long>(m0 + nm),
+                static_cast<long long>(p->M));
+  MI355_REQUIRE(C > 0, "C must be positive");
+  MI355_HIP(hipSetDevice(c->device));
+  const int64_t n = nm * C;
+  const int ngrp = (C + kBeamCH - 1) / kBeamCH;
+  // pixels per block: enough blocks to fill 256 CUs several times over, at least 512 pixels each
+  int64_t want = ceil_div64(4096, nm * ngrp);
+  int64_t nchunk = std::max<int64_t>(1, std::min<int64_t>(want, ceil_div64(p->npix, 512)));
+  int64_t chunk = ceil_div64(ceil_div64(p->npix, nchunk), 256) * 256;
+  nchunk = ceil_div64(p->npix, chunk);
+  if (p->partial.alloc(static_cast<size_t>(n) * nchunk)) return -2;
+  BeamArgs a{};
+  a.x = p->x.p;
+  a.y = p->y.p;
+  a.xy_per_map = p->xy_per_map;
+  a.d = p->d.p;
+  a.w = p->w.p;
+  a.w_kind = p->sig_kind;
+  a.npix = p->npix;
+  a.C = C;
+  a.n = n;
+  a.theta = theta_dev;
+  a.chunk = static_cast<int>(chunk);
+  a.nchunk = static_cast<int>(nchunk);
+  a.partial = p->partial.p;
+  MI355_HIP(hipEventRecord(c->ev0, c->stream));
+  // blockIdx.y is limited to 65535: slabs of maps
+  for (int64_t s0 = 0; s0 < nm; s0 += 32768) {
+    const int64_t ns = std::min<int64_t>(32768, nm - s0);
+    BeamArgs b = a;
+    b.m0 = m0 + s0;
+    b.theta = theta_dev + s0 * C;           // vector e = (m - b.m0)*C + c, stride n between params
+    b.partial = p->partial.p + s0 * C * nchunk;
+    hipLaunchKernelGGL(k_beam_chi2, dim3(static_cast<unsigned>(nchunk), static_cast<unsigned>(ns), ngrp),
+                       dim3(256), 0, c->stream, b);
+    MI355_HIP(hipGetLastError());
+  }
+  MI355_HIP(hipEventRecord(c->ev1, c->stream));
+  c->ev_valid = true;
+  hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
+                     c->stream, n, static_cast<int>(nchunk), p->partial.p, lnL_dev);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+int mi355_beam_lnlike(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta,
+                      double* lnL) {
+  if (beam_ready(c, "mi355_beam_lnlike")) return -1;
+  MI355_REQUIRE(theta && lnL && nm > 0 && C > 0, "mi355_beam_lnlike: bad argument");
+  MI355_HIP(hipSetDevice(c->device));
+  BeamProblem* p = c->beam;
+  const int64_t n = nm * C;
+  const size_t nt = static_cast<size_t>(n) * kBeamP;
+  if (p->theta_in.alloc(nt) || p->theta_pm.alloc(nt) || p->lnl.alloc(static_cast<size_t>(n))) return -2;
+  MI355_HIP(hipMemcpyAsync(p->theta_in.p, theta, nt * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_beam_to_pm, dim3(static_cast<unsigned>(ceil_div64(nt, 256))), dim3(256), 0,
+                     c->stream, n, p->theta_in.p, p->theta_pm.p);
+  MI355_HIP(hipGetLastError());
+  int rc = mi355_beam_lnlike_dev_async(c, m0, nm, C, p->theta_pm.p, p->lnl.p);
+  if (rc) return rc;
+  MI355_HIP(hipMemcpyAsync(lnL, p->lnl.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_beam_prior_package(mi355_ctx* c, int64_t n, const double* theta, double* prior,
+                             double* packaged) {
+  if (beam_ready(c, "mi355_beam_prior_package")) return -1;
+  MI355_REQUIRE(theta && n > 0, "mi355_beam_prior_package: empty batch");
+  MI355_HIP(hipSetDevice(c->device));
+  BeamProblem* p = c->beam;
+  const size_t nt = static_cast<size_t>(n) * kBeamP;
+  if (p->theta_in.alloc(nt) || p->tmp.alloc(nt + n)) return -2;
+  MI355_HIP(hipMemcpyAsync(p->theta_in.p, theta, nt * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_beam_prior_package, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256),
+                     0, c->stream, n, p->theta_in.p, p->box, prior ? p->tmp.p + nt : nullptr,
+                     packaged ? p->tmp.p : nullptr);
+  MI355_HIP(hipGetLastError());
+  if (prior) MI355_HIP(hipMemcpyAsync(prior, p->tmp.p + nt, n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (packaged) MI355_HIP(hipMemcpyAsync(packaged, p->tmp.p, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_beam_model(mi355_ctx* c, int64_t n, const double* theta, int64_t npts, const double* x,
+                     const double* y, double* out) {
+  MI355_REQUIRE(c && theta && x && y && out && n > 0 && npts > 0, "mi355_beam_model: bad argument");
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t nt = static_cast<size_t>(n) * kBeamP, no = static_cast<size_t>(n) * npts;
+  if (c->scratch_a.alloc(nt + 2 * npts) || c->scratch_b.alloc(no)) return -2;
+  double* dt = c->scratch_a.p;
+  double* dx = dt + nt;
+  double* dy = dx + npts;
+  MI355_HIP(hipMemcpyAsync(dt, theta, nt * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(dx, x, npts * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(dy, y, npts * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_beam_model, dim3(static_cast<unsigned>(ceil_div64(no, 256))), dim3(256), 0,
+                     c->stream, n, dt, npts, dx, dy, c->scratch_b.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(out, c->scratch_b.p, no * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mi355_beam_stats(mi355_ctx* c, int64_t m, int32_t has_sigcut, double sigcut, int32_t do_abs,
+                     double* out) {
+  if (beam_ready(c, "mi355_beam_stats")) return -1;
+  BeamProblem* p = c->beam;
+  MI355_REQUIRE(out && m >= 0 && m < p->M, "mi355_beam_stats: map %lld outside [0,%lld)",
+                static_cast<long long>(m), static_cast<long long>(p->M));
+  MI355_HIP(hipSetDevice(c->device));
+  if (p->tmp.alloc(4)) return -2;
+  const double* xs = p->x.p + (p->xy_per_map ? m * p->npix : 0);
+  const double* ys = p->y.p + (p->xy_per_map ? m * p->npix : 0);
+  const double* sg = p->sig.p + (p->sig_kind == 2 ? m * p->npix : (p->sig_kind == 1 ? m : 0));
+  hipLaunchKernelGGL(k_beam_stats, dim3(1), dim3(256), 0, c->stream, p->npix, xs, ys,
+                     p->d.p + m * p->npix, sg, p->sig_kind == 2 ? 1 : 0, has_sigcut, sigcut, do_abs,
+                     p->tmp.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(out, p->tmp.p, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ClDataset, Mi355Error, SedModel, c_double_p, c_int32_p, c_int64_p, c_uint8_p, check
+from ._lib import BeamPrior, ClDataset, Mi355Error, SedModel, c_double_p, c_int32_p, c_int64_p, c_uint8_p, check
 
 MODEL_IDS = {"M1N": 0, "M1N_LOGA": 1, "M2N": 2, "M2N_LOGA": 3, "M1": 4, "M2": 5, "THICK": 6,
              "THICK_LOGA": 7}
@@ -372,6 +372,79 @@ class Engine:
         check(self.lib.mi355_cl_calc_lnlike(self._h, int(idata), a.shape[0], _dp(a), a.shape[1],
                                             a.shape[2], _dp(out)))
         return float(out[0]) if single else out
+
+    # ---- BeamFit -----------------------------------------------------------------------------
+    def beam_load(self, x, y, d, sig, center_min=None, center_max=None, sig_min=None, sig_max=None):
+        """d [M, npix] (or [npix]); x, y [npix] shared or [M, npix]; sig scalar, [M] or [M, npix]."""
+        d = _f64(d)
+        if d.ndim == 1:
+            d = d[None]
+        M, npix = d.shape
+        x, y = _f64(x), _f64(y)
+        per_map = int(x.ndim == 2)
+        if x.shape != y.shape or x.shape[-1] != npix or (per_map and x.shape[0] != M):
+            raise ValueError("DataSizeError: x, y must be [npix] or [M, npix] matching d")
+        sig = _f64(np.atleast_1d(sig))
+        if sig.size == 1:
+            kind = 0
+        elif sig.shape == (M,) and M != npix:
+            kind = 1
+        elif sig.size == M * npix:
+            kind, sig = 2, _f64(sig.reshape(M, npix))
+        else:
+            raise ValueError("DataSizeError: %d data points but %d sigmas" % (npix, sig.size))
+        pr = BeamPrior()
+        pr.has_center = int(center_min is not None)
+        if center_min is not None:
+            pr.center_min[0], pr.center_min[1] = float(center_min[0]), float(center_min[1])
+            pr.center_max[0], pr.center_max[1] = float(center_max[0]), float(center_max[1])
+        pr.has_sig_min = int(sig_min is not None)
+        pr.sig_min = float(sig_min) if sig_min is not None else 0.0
+        pr.has_sig_max = int(sig_max is not None)
+        pr.sig_max = float(sig_max) if sig_max is not None else 0.0
+        check(self.lib.mi355_beam_load(self._h, M, npix, _dp(x), _dp(y), per_map, _dp(d), _dp(sig),
+                                       kind, C.byref(pr)))
+        self.beam_M, self.beam_npix = M, npix
+
+    def beam_lnlike(self, theta, m0=0):
+        """theta [nm, C, 9] -> lnL [nm, C]; [9] -> float (map m0)."""
+        theta = _f64(theta)
+        single = theta.ndim == 1
+        th = theta.reshape(1, 1, 9) if single else (theta[None] if theta.ndim == 2 else theta)
+        nm, Cc, _ = th.shape
+        out = np.empty((nm, Cc))
+        check(self.lib.mi355_beam_lnlike(self._h, int(m0), nm, Cc, _dp(_f64(th)), _dp(out)))
+        if single:
+            return float(out[0, 0])
+        return out[0] if theta.ndim == 2 else out
+
+    def beam_lnlike_dev(self, theta_ptr, lnl_ptr, nm, Cc, m0=0):
+        check(self.lib.mi355_beam_lnlike_dev_async(self._h, int(m0), int(nm), int(Cc),
+                                                   C.c_void_p(theta_ptr), C.c_void_p(lnl_ptr)))
+
+    def beam_prior_package(self, theta):
+        theta = _f64(theta)
+        flat = _f64(theta.reshape(-1, 9))
+        pr = np.empty(flat.shape[0])
+        pk = np.empty_like(flat)
+        check(self.lib.mi355_beam_prior_package(self._h, flat.shape[0], _dp(flat), _dp(pr), _dp(pk)))
+        return pr.reshape(theta.shape[:-1]), pk.reshape(theta.shape)
+
+    def beam_model(self, theta, x, y):
+        theta = _f64(theta)
+        single = theta.ndim == 1
+        flat = _f64(theta.reshape(-1, 9))
+        x, y = _f64(x).reshape(-1), _f64(y).reshape(-1)
+        out = np.empty((flat.shape[0], x.size))
+        check(self.lib.mi355_beam_model(self._h, flat.shape[0], _dp(flat), x.size, _dp(x), _dp(y), _dp(out)))
+        return out[0] if single else out
+
+    def beam_stats(self, m=0, sigcut=None, do_abs=False):
+        out = np.empty(4)
+        check(self.lib.mi355_beam_stats(self._h, int(m), int(sigcut is not None),
+                                        float(sigcut) if sigcut is not None else 0.0, int(do_abs),
+                                        _dp(out)))
+        return tuple(out)
 
     # ---- Gelman-Rubin ----------------------------------------------------------------------
     def rhat(self):
