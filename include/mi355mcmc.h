@@ -271,6 +271,43 @@ int mi355_beam_model(mi355_ctx* ctx, int64_t n, const double* theta, int64_t npt
 int mi355_beam_stats(mi355_ctx* ctx, int64_t m, int32_t has_sigcut, double sigcut, int32_t do_abs,
                      double* out);
 
+/* ---- step-wise Metropolis-Hastings over any problem kind ---------------------------------- */
+/* mi355_mh_init (above) starts the fused SED sampler: one kernel launch advances a chain many
+ * steps, uncorrelated proposals.  mi355_mh_init_problem starts the step-wise sampler instead: one
+ * MH step = propose kernel -> the problem's batched likelihood -> accept kernel.  It serves the
+ * problems whose likelihood is itself a kernel pipeline (binnedCl, BeamFit) and every proposal of
+ * Proposal.py, including the Cholesky-correlated (:150-154) and rotated (:145-148) ones, for all
+ * three problem kinds.  After it, mi355_mh_run / _moments / _sigmas / _trace / _adapt / mi355_rhat*
+ * act on the step-wise chains (same buffers, same layouts).
+ *  problem : MI355_PROBLEM_SED (catalogue of mi355_sed_load: S sources x C chains),
+ *            MI355_PROBLEM_CL  (mi355_cl_load + mi355_cl_set_binning: 1 x C chains),
+ *            MI355_PROBLEM_BEAM (mi355_beam_load: M maps x C chains)
+ *  track_cov : 1 = keep running co-moments so that covar() / correlated restarts need no trace
+ *  other arguments as mi355_mh_init; the draw-injection contract of mi355_mh_run is the same, and
+ *  in rotated mode the k-th member of the block takes element k of the step's row of normals. */
+enum mi355_problem_kind { MI355_PROBLEM_SED = 0, MI355_PROBLEM_CL = 1, MI355_PROBLEM_BEAM = 2 };
+int mi355_mh_init_problem(mi355_ctx* ctx, int32_t problem, int32_t C, const double* theta0,
+                          int32_t theta0_per_chain, const double* sigma, int32_t sigma_per_chain,
+                          const int32_t* param_blocks, int32_t nblock, int32_t randomize_start,
+                          int32_t track_cov);
+/* prop.setNormalizedMatrixFromSqrt(L) + prop.rotateParams = rotate (Proposal.py:106-109, :78):
+ * L host [P,P] (per_chain=0) or [S,C,P,P] (=1); NULL returns to uncorrelated proposals. */
+int mi355_mh_set_sqrt_matrix(mi355_ctx* ctx, const double* L, int32_t per_chain, int32_t rotate);
+/* newMCMC(burn=1, fac, random, noCorrelations, rotateParams, doBlock) for every chain
+ * (MCMC.py:343-413): restart at package(mean), sigma = package(fac*stdev), and unless
+ * no_correlations the Cholesky factor of the normalised covariance over the parameters with
+ * sigma>0 (Proposal.py:81-101; +0.01 on the diagonal if it is not positive definite,
+ * MCMC.py:397-399).  do_block: 1 / 0 = doBlock True / False, -1 = keep (MCMC.py:382-383). */
+int mi355_mh_adapt_corr(mi355_ctx* ctx, double fac, int32_t random_restart, int32_t no_correlations,
+                        int32_t rotate, int32_t do_block);
+/* covar(burn=1) of every chain (MCMC.py:310-340) from the running co-moments: host [S,C,P,P];
+ * normalized=1 divides by stdev_i*stdev_j. */
+int mi355_mh_covar(mi355_ctx* ctx, double* cov, int32_t normalized);
+/* prop.sqrtMatrix of every chain: host [S,C,P,P]. */
+int mi355_mh_get_sqrt_matrix(mi355_ctx* ctx, double* L);
+/* 0 uncorrelated, 1 Cholesky-correlated, 2 rotated */
+int32_t mi355_mh_proposal_mode(mi355_ctx* ctx);
+
 /* ---- Gelman-Rubin: MCMC/convergence.py:58-87 -------------------------------------------- */
 /* Per-source partial sums over this context's C chains, for an all-reduce across GPUs that
  * hold different chains of the same sources (chain-sharded layout).  dev buffers:

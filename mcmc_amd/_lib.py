@@ -98,6 +98,15 @@ SIGNATURES = {
     "mi355_beam_model": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_int64, c_double_p, c_double_p,
                                    c_double_p]),
     "mi355_beam_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, c_double_p]),
+    "mi355_mh_init_problem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32,
+                                        c_double_p, C.c_int32, c_int32_p, C.c_int32, C.c_int32,
+                                        C.c_int32]),
+    "mi355_mh_set_sqrt_matrix": (C.c_int, [C.c_void_p, c_double_p, C.c_int32, C.c_int32]),
+    "mi355_mh_adapt_corr": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32]),
+    "mi355_mh_covar": (C.c_int, [C.c_void_p, c_double_p, C.c_int32]),
+    "mi355_mh_get_sqrt_matrix": (C.c_int, [C.c_void_p, c_double_p]),
+    "mi355_mh_proposal_mode": (C.c_int32, [C.c_void_p]),
     "mi355_rhat_partial_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi355_rhat_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mi355_gelman_rubin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),

@@ -225,6 +225,7 @@ void mi355_free(mi355_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   cl_destroy(c->cl);
   beam_destroy(c->beam);
+  gmh_destroy(c->gmh);
   delete c;
 }
 
@@ -425,7 +426,7 @@ int mi355_sed_prior_package(mi355_ctx* c, int64_t n, const double* theta, double
 // upload a host [N][P] (per_chain) or [P] array as device [P][N] / [P]
 static int upload_param(mi355_ctx* c, const double* host, int per_chain, DevBuf<double>& tmp,
                         DevBuf<double>& out) {
-  const int P = c->P;
+  const int P = c->mhP;
   if (!per_chain) {
     if (out.alloc(static_cast<size_t>(P))) return -2;
     MI355_HIP(hipMemcpyAsync(out.p, host, P * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -449,10 +450,13 @@ int mi355_mh_init(mi355_ctx* c, int32_t C, const double* theta0, int32_t theta0_
   MI355_REQUIRE(nblock >= 0 && nblock <= c->P, "nblock=%d outside [0,%d]", nblock, c->P);
   MI355_REQUIRE(nblock == 0 || param_blocks, "param_blocks required when nblock>0");
   MI355_HIP(hipSetDevice(c->device));
-  const int P = c->P;
+  c->mhP = c->P;
+  c->mhS = c->S;
+  if (c->gmh) gmh_deactivate(c);
+  const int P = c->mhP;
   c->mh_ready = false;
   c->C = C;
-  c->N = c->S * C;
+  c->N = c->mhS * C;
   c->nblock = nblock;
   int maxblk = 1;
   for (int b = 0; b < kMaxParam; ++b) c->blockmask[b] = 0;
@@ -500,12 +504,13 @@ int mi355_mh_init(mi355_ctx* c, int32_t C, const double* theta0, int32_t theta0_
 int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_normals,
                  const double* inj_uniforms) {
   MI355_REQUIRE(c && c->mh_ready, "mi355_mh_run: chains not initialised (call mi355_mh_init)");
+  if (gmh_active(c)) return gmh_run(c, nsteps, thin, inj_normals, inj_uniforms);
   MI355_REQUIRE(nsteps >= 0 && thin >= 0, "negative nsteps/thin");
   MI355_REQUIRE((inj_normals == nullptr) == (inj_uniforms == nullptr),
                 "inj_normals and inj_uniforms must be given together");
   if (nsteps == 0) return 0;
   MI355_HIP(hipSetDevice(c->device));
-  const int P = c->P;
+  const int P = c->mhP;
   MhArgs a = base_args(c);
   a.nsteps = nsteps;
   a.thin = thin;
@@ -556,7 +561,7 @@ int64_t mi355_mh_ntrace(mi355_ctx* c) { return c ? c->nkeep : -1; }
 
 // device [P][N] -> host [N][P]
 static int download_param(mi355_ctx* c, const double* dev, double* host, double scale) {
-  const int P = c->P;
+  const int P = c->mhP;
   const size_t n = static_cast<size_t>(c->N) * P;
   std::vector<double> tmp(n);
   MI355_HIP(hipMemcpyAsync(tmp.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -606,7 +611,7 @@ int mi355_mh_trace(mi355_ctx* c, double* samples, double* lnPr, uint8_t* accepte
   MI355_REQUIRE(c && c->mh_ready, "mi355_mh_trace: chains not initialised");
   MI355_REQUIRE(c->nkeep > 0, "mi355_mh_trace: the last mi355_mh_run kept no trace (thin=0)");
   MI355_HIP(hipSetDevice(c->device));
-  const int P = c->P;
+  const int P = c->mhP;
   const size_t rows = static_cast<size_t>(c->nkeep) * c->N;
   if (samples) {
     std::vector<double> tmp(rows * P);
@@ -630,8 +635,9 @@ int mi355_mh_trace(mi355_ctx* c, double* samples, double* lnPr, uint8_t* accepte
 int mi355_mh_adapt(mi355_ctx* c, double fac, int32_t random_restart) {
   MI355_REQUIRE(c && c->mh_ready, "mi355_mh_adapt: chains not initialised");
   MI355_REQUIRE(c->nsamp > 0, "mi355_mh_adapt: no samples to adapt from");
+  if (gmh_active(c)) return gmh_adapt(c, fac, random_restart, 1, 0, -1);
   MI355_HIP(hipSetDevice(c->device));
-  if (!(fac > 0.0)) fac = 2.4 / std::sqrt(static_cast<double>(c->P));   // MCMC.py:379-380
+  if (!(fac > 0.0)) fac = 2.4 / std::sqrt(static_cast<double>(c->mhP));   // MCMC.py:379-380
   MhArgs a = base_args(c);
   a.adapt = 1;
   a.fac = fac;
@@ -719,9 +725,9 @@ int mi355_rhat_partial_async(mi355_ctx* c, int32_t pass, const double* gmean_dev
   MI355_REQUIRE(c->nsamp > 0, "mi355_rhat: no samples accumulated yet");
   MI355_REQUIRE(sums_dev && (pass == 0 || gmean_dev), "mi355_rhat_partial: null buffer");
   MI355_HIP(hipSetDevice(c->device));
-  const int64_t waves = c->S * c->P;
+  const int64_t waves = c->mhS * c->mhP;
   hipLaunchKernelGGL(k_rhat_partial, dim3(static_cast<unsigned>(ceil_div(waves * 64, kBlockThreads))),
-                     dim3(kBlockThreads), 0, c->stream, pass, c->P, c->S, c->C, c->N,
+                     dim3(kBlockThreads), 0, c->stream, pass, c->mhP, c->mhS, c->C, c->N,
                      1.0 / static_cast<double>(c->nsamp), c->mean.p, c->m2.p, gmean_dev, sums_dev);
   MI355_HIP(hipGetLastError());
   return 0;
@@ -732,7 +738,7 @@ int mi355_rhat_finish_async(mi355_ctx* c, const double* sums_dev, int64_t Ctot, 
   MI355_REQUIRE(Ctot >= 2, "Gelman-Rubin needs at least 2 chains per source (got %lld)",
                 static_cast<long long>(Ctot));
   MI355_HIP(hipSetDevice(c->device));
-  const int64_t n = c->S * c->P;
+  const int64_t n = c->mhS * c->mhP;
   hipLaunchKernelGGL(k_rhat_finish, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0,
                      c->stream, n, static_cast<double>(Ctot), sums_dev, rhat_dev);
   MI355_HIP(hipGetLastError());
@@ -760,7 +766,7 @@ int mi355_gelman_rubin(mi355_ctx* c, int32_t nchain, int32_t P, const double* me
 
 int mi355_rhat(mi355_ctx* c, double* rhat) {
   MI355_REQUIRE(c && c->mh_ready && rhat, "mi355_rhat: bad argument");
-  const int64_t n = c->S * c->P;
+  const int64_t n = c->mhS * c->mhP;
   if (c->scratch_a.alloc(static_cast<size_t>(n) * 4)) return -2;
   double* gmean = c->scratch_a.p;
   double* sums = c->scratch_a.p + n;
@@ -776,8 +782,8 @@ int mi355_rhat(mi355_ctx* c, double* rhat) {
   std::vector<double> h(static_cast<size_t>(n));
   MI355_HIP(hipMemcpyAsync(h.data(), out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MI355_HIP(hipStreamSynchronize(c->stream));
-  for (int p = 0; p < c->P; ++p)
-    for (int64_t s = 0; s < c->S; ++s) rhat[s * c->P + p] = h[p * c->S + s];
+  for (int p = 0; p < c->mhP; ++p)
+    for (int64_t s = 0; s < c->mhS; ++s) rhat[s * c->mhP + p] = h[p * c->mhS + s];
   return 0;
 }
 

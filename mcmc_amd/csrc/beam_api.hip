@@ -3,6 +3,7 @@
 #include <memory>
 
 #include "beam_kernels.hpp"
+#include "problems.hpp"
 
 namespace mi355 {
 
@@ -15,6 +16,13 @@ struct BeamProblem {
 };
 
 void beam_destroy(BeamProblem* p) { delete p; }
+
+int beam_problem_info(const mi355_ctx* c, int64_t* M, BeamPriorBox* box) {
+  if (!c || !c->beam || c->beam->M <= 0) return -1;
+  *M = c->beam->M;
+  *box = c->beam->box;
+  return 0;
+}
 
 static int beam_ready(mi355_ctx* c, const char* who) {
   MI355_REQUIRE(c && c->beam && c->beam->M > 0, "%s: no beam maps loaded (call mi355_beam_load)", who);

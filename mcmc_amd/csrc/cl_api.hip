@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "cl_kernels.hpp"
+#include "problems.hpp"
 
 namespace mi355 {
 
@@ -30,6 +31,13 @@ struct ClProblem {
 };
 
 void cl_destroy(ClProblem* p) { delete p; }
+
+int cl_problem_info(const mi355_ctx* c, int* npar, const int32_t** cltype_dev) {
+  if (!c || !c->cl || !c->cl->binned) return -1;
+  *npar = c->cl->npar;
+  *cltype_dev = c->cl->cltype.p;
+  return 0;
+}
 
 template <typename T>
 static int upload(mi355_ctx* c, DevBuf<T>& buf, const T* host, size_t n, size_t n_alloc = 0) {

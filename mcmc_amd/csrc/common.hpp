@@ -104,6 +104,8 @@ struct mi355_ctx {
   bool mh_ready = false;
   int C = 0;
   int64_t N = 0;
+  int mhP = 0;                    // parameters per chain of the running sampler
+  int64_t mhS = 0;                // chain groups (sources / maps; 1 for binnedCl): N = mhS*C
   int nblock = 0;                 // 0: doBlock=False
   uint32_t blockmask[mi355::kMaxParam] = {0};
   int32_t rank_in_block[mi355::kMaxParam] = {0};
@@ -129,3 +131,12 @@ struct mi355_ctx {
   mi355::BeamProblem* beam = nullptr;   // BeamFit maps
   mi355::GmhState* gmh = nullptr;       // step-wise Metropolis-Hastings over any problem kind
 };
+
+namespace mi355 {
+// step-wise sampler hooks (gmh_api.hip) used by the shared mi355_mh_* entry points
+bool gmh_active(const mi355_ctx* c);
+void gmh_deactivate(mi355_ctx* c);
+int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, const double* inj_u);
+int gmh_adapt(mi355_ctx* c, double fac, int random_restart, int no_correlations, int rotate,
+              int do_block);
+}  // namespace mi355

@@ -92,6 +92,7 @@ class Engine:
                                       _dp(nu), _dp(d), _dp(sig)))
         self.model = m
         self.P, self.S, self.nb_max = int(m.nparam), int(S), int(nbm)
+        self.S_sed = int(S)
         self.C = 0
 
     def sed_lnlike(self, theta, s0=0, derived=False):
@@ -136,6 +137,7 @@ class Engine:
         theta0 = _f64(theta0)
         sigma = _f64(sigma)
         Cc = int(C_chains)
+        self.P, self.S = int(self.model.nparam), self.S_sed     # (a step-wise sampler may have changed them)
         per_t = int(theta0.ndim > 1)
         per_s = int(sigma.ndim > 1)
         if per_t:
@@ -157,6 +159,78 @@ class Engine:
                                      pb.ctypes.data_as(c_int32_p) if pb is not None else None,
                                      nblock, int(bool(randomize_start))))
         self.C, self.nblock = Cc, nblock
+
+    PROBLEMS = {"sed": 0, "cl": 1, "beam": 2}
+
+    def mh_init_problem(self, problem, C_chains, theta0, sigma, param_blocks=None,
+                        randomize_start=True, track_cov=False):
+        """Step-wise sampler over the loaded problem ("sed", "cl" or "beam"): any proposal of
+        Proposal.py (uncorrelated, Cholesky-correlated, rotated).  Chain layout [units, C, P] with
+        units = sources (sed), 1 (cl) or maps (beam)."""
+        kind = self.PROBLEMS[problem] if isinstance(problem, str) else int(problem)
+        if kind == 0:
+            P, S = int(self.model.nparam), self.S_sed
+        elif kind == 1:
+            P, S = self.cl_npar, 1
+        else:
+            P, S = 9, self.beam_M
+        Cc = int(C_chains)
+        theta0, sigma = _f64(theta0), _f64(sigma)
+        per_t, per_s = int(theta0.ndim > 1), int(sigma.ndim > 1)
+        if per_t:
+            theta0 = _f64(theta0.reshape(S, Cc, P))
+        elif theta0.shape != (P,):
+            raise ValueError("theta0 must be [P] or [units,C,P]")
+        if per_s:
+            sigma = _f64(sigma.reshape(S, Cc, P))
+        elif sigma.shape != (P,):
+            raise ValueError("sigma must be [P] or [units,C,P]")
+        if param_blocks is None:
+            pb, nblock = None, 0
+        else:
+            pb = np.ascontiguousarray(param_blocks, dtype=np.int32)
+            if pb.shape[0] < P:                       # parameters beyond the table are in no block
+                pb = np.concatenate([pb, np.full(P - pb.shape[0], -1, np.int32)])
+            pb = np.ascontiguousarray(pb[:P])
+            nblock = int(pb.max()) + 1
+        check(self.lib.mi355_mh_init_problem(
+            self._h, kind, Cc, _dp(theta0), per_t, _dp(sigma), per_s,
+            pb.ctypes.data_as(c_int32_p) if pb is not None else None, nblock,
+            int(bool(randomize_start)), int(bool(track_cov))))
+        self.P, self.S, self.C, self.nblock = P, S, Cc, nblock
+
+    def mh_set_sqrt_matrix(self, L, rotate=False):
+        if L is None:
+            check(self.lib.mi355_mh_set_sqrt_matrix(self._h, None, 0, 0))
+            return
+        L = _f64(L)
+        per = int(L.ndim > 2)
+        L = _f64(L.reshape(self.S, self.C, self.P, self.P)) if per else _f64(L, (self.P, self.P))
+        check(self.lib.mi355_mh_set_sqrt_matrix(self._h, _dp(L), per, int(bool(rotate))))
+
+    def mh_adapt_corr(self, fac=None, random_restart=False, no_correlations=False, rotate=False,
+                      do_block=None):
+        """newMCMC() for every chain, with the correlated / rotated proposals of the reference."""
+        db = -1 if do_block is None else int(bool(do_block))
+        check(self.lib.mi355_mh_adapt_corr(self._h, float(fac) if fac else 0.0,
+                                           int(bool(random_restart)), int(bool(no_correlations)),
+                                           int(bool(rotate)), db))
+        if do_block is not None and not do_block:
+            self.nblock = 0
+
+    def mh_covar(self, normalized=True):
+        out = np.empty((self.S, self.C, self.P, self.P))
+        check(self.lib.mi355_mh_covar(self._h, _dp(out), int(bool(normalized))))
+        return out
+
+    def mh_sqrt_matrix(self):
+        out = np.empty((self.S, self.C, self.P, self.P))
+        check(self.lib.mi355_mh_get_sqrt_matrix(self._h, _dp(out)))
+        return out
+
+    @property
+    def proposal_mode(self):
+        return int(self.lib.mi355_mh_proposal_mode(self._h))
 
     def mh_run(self, nsteps, thin=0, inj_normals=None, inj_uniforms=None):
         if inj_normals is not None:

@@ -1,0 +1,234 @@
+"""The step-wise Metropolis-Hastings engine (mi355_mh_init_problem: any problem kind, correlated
+and rotated proposals) against the reference's own chains (golden fixtures, injected draws), the
+oracle on the device's Philox streams, and the fused SED kernel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-12
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def replay(eng, g, tag, rows, nsteps, P):
+    """inject rows [rows, rows+nsteps) of the fixture's draw streams, compare with chain `tag`"""
+    zn = g["chain__normals"][rows:rows + nsteps, None, :P]
+    zu = g["chain__uniforms"][rows:rows + nsteps, None]
+    eng.mh_run(nsteps, thin=1, inj_normals=np.ascontiguousarray(zn), inj_uniforms=np.ascontiguousarray(zu))
+    s, l, a = eng.mh_trace()
+    ref_s, ref_l = g["chain__%s_samples" % tag], g["chain__%s_lnPr" % tag]
+    ref_a = g["chain__%s_accepted" % tag]
+    assert np.array_equal(a[:, 0, 0], ref_a[1:])
+    np.testing.assert_allclose(s[:, 0, 0], ref_s[1:], rtol=RTOL, atol=1e-15)
+    np.testing.assert_allclose(l[:, 0, 0], ref_l[1:], rtol=RTOL)
+    mom = eng.mh_moments()
+    assert int(mom["naccept"][0, 0]) == int(g["chain__%s_naccept" % tag])
+    np.testing.assert_allclose(mom["mean"][0, 0], ref_s[1:].mean(axis=0), rtol=1e-10)
+    # (numpy's two-pass variance of a column that never moved is rounding noise ~1e-28, ours is 0)
+    np.testing.assert_allclose(mom["var"][0, 0], ref_s[1:].var(axis=0), rtol=1e-8,
+                               atol=1e-24 * float(np.max(ref_s ** 2)))
+    return mom
+
+
+def cl_engine(g, name="xcalib"):
+    from test_cl_gpu import mirror
+    from mcmc_amd import Engine
+    model, d = mirror(g, name)
+    eng = Engine()
+    eng.cl_load([d])
+    eng.cl_set_binning(model.bins, model.shapefun)
+    return eng, model
+
+
+def test_cl_reference_chains_block_rotated_correlated():
+    g = load("cl_g5.npz")
+    eng, model = cl_engine(g)
+    P = model.nparam
+    k = g["chain__k"]
+    blocks = np.arange(P)
+    with eng:
+        # stage 0: doBlock, uncorrelated, 400 steps of the reference's chain
+        eng.mh_init_problem("cl", 1, g["chain__c0_samples"][0], np.full(P, 0.05), param_blocks=blocks,
+                            randomize_start=False, track_cov=True)
+        mom = replay(eng, g, "c0", k[0], 400, P)
+        assert np.array_equal(mom["accept"][0, 0], g["chain__accept0"])
+        # newMCMC(rotateParams=True) on the device: sigma = 2.4/sqrt(P)*stdev, Cholesky of the
+        # normalised covariance (MCMC.py:343-413) - against the reference's new proposal
+        ref = g["chain__c0_samples"][1:]
+        cov = eng.mh_covar(normalized=False)[0, 0]
+        np.testing.assert_allclose(cov, np.cov(ref.T, bias=True), rtol=1e-8, atol=1e-18)
+        eng.mh_adapt_corr(rotate=True)
+        assert eng.proposal_mode == 2
+        np.testing.assert_allclose(eng.mh_sigmas()[0, 0], g["chain__c1_sigmas"], rtol=1e-9)
+        np.testing.assert_allclose(eng.mh_sqrt_matrix()[0, 0], g["chain__c1_sqrt"], rtol=1e-7, atol=1e-9)
+        # stage 1 draw for draw: the reference's start, widths and sqrt matrix, rotated proposals
+        eng.mh_init_problem("cl", 1, g["chain__c1_samples"][0], g["chain__c1_sigmas"],
+                            param_blocks=blocks, randomize_start=False, track_cov=True)
+        eng.mh_set_sqrt_matrix(g["chain__c1_sqrt"], rotate=True)
+        mom = replay(eng, g, "c1", k[2], 300, P)
+        assert np.array_equal(mom["accept"][0, 0], g["chain__accept1"])
+        eng.mh_adapt_corr(no_correlations=False, do_block=False)
+        assert eng.proposal_mode == 1
+        np.testing.assert_allclose(eng.mh_sqrt_matrix()[0, 0], g["chain__c2_sqrt"], rtol=1e-7, atol=1e-9)
+        # stage 2: all parameters at once through the Cholesky factor
+        eng.mh_init_problem("cl", 1, g["chain__c2_samples"][0], g["chain__c2_sigmas"],
+                            param_blocks=None, randomize_start=False)
+        eng.mh_set_sqrt_matrix(g["chain__c2_sqrt"], rotate=False)
+        replay(eng, g, "c2", k[4], 200, P)
+
+
+def test_beam_reference_chains():
+    from mcmc_amd import Engine
+    g = load("beam_g6.npz")
+    k = g["chain__k"]
+    sig = g["m64a__sig"]
+    with Engine() as eng:
+        eng.beam_load(g["m64a__x"], g["m64a__y"], g["m64a__d"], sig[0], center_min=g["centerMin"],
+                      center_max=g["centerMax"], sig_min=float(g["sigMin"]), sig_max=float(g["sigMax"]))
+        blocks = np.arange(7)                      # ProcessBeamData.py:215-216 (mu, phi in no block)
+        eng.mh_init_problem("beam", 1, g["chain__c0_samples"][0], g["chain__sigmas"],
+                            param_blocks=blocks, randomize_start=False, track_cov=True)
+        mom = replay(eng, g, "c0", k[0], 500, 9)
+        assert np.array_equal(mom["accept"][0, 0], g["chain__c0_accept"])
+        covn = eng.mh_covar(normalized=True)[0, 0]
+        eng.mh_adapt_corr(no_correlations=False)
+        # x never moved in this stage: the reference's stdev of that column is rounding noise
+        # (1.3e-14, so it stays in the Cholesky subset with noise correlations), ours is exactly 0
+        # and the parameter drops out as a fixed one (Proposal.py:85-101).  Compare what is defined.
+        moved = g["chain__c1_sigmas"] > 1e-10
+        sg = eng.mh_sigmas()[0, 0]
+        np.testing.assert_allclose(sg[moved], g["chain__c1_sigmas"][moved], rtol=1e-9)
+        assert np.all(sg[~moved] == 0)
+        L = eng.mh_sqrt_matrix()[0, 0]
+        sub = np.ix_(sg > 0, sg > 0)
+        np.testing.assert_allclose((L @ L.T)[sub], covn[sub], rtol=1e-10, atol=1e-12)
+        assert np.all(L[~(sg > 0)] == 0) and np.all(np.triu(L, 1) == 0)
+        eng.mh_init_problem("beam", 1, g["chain__c1_samples"][0], g["chain__c1_sigmas"],
+                            param_blocks=blocks, randomize_start=False)
+        eng.mh_set_sqrt_matrix(g["chain__c1_sqrt"], rotate=False)
+        mom = replay(eng, g, "c1", k[2], 300, 9)
+        assert np.array_equal(mom["accept"][0, 0], g["chain__c1_accept"])
+
+
+def test_sed_stepwise_equals_fused_kernel():
+    """Same seed, same Philox streams: the step-wise engine and the fused kernel must produce the
+    same chains bit for bit (same likelihood code, same accept rule, same moment updates)."""
+    from mcmc_amd import Engine, synth
+    S, C, n1, n2 = 5, 64, 120, 80
+    nu, d, sig, _ = synth.sed_catalogue(S, seed=3)
+    nb = np.full(S, 8, np.int32)
+    out = []
+    for stepwise in (False, True):
+        with Engine(seed=99) as eng:
+            eng.sed_load("M2N", nb, nu, d, sig)
+            if stepwise:
+                eng.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS,
+                                    param_blocks=np.arange(6), randomize_start=True)
+            else:
+                eng.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
+                            randomize_start=True)
+            eng.mh_run(n1, thin=1)
+            t1 = eng.mh_trace()
+            eng.mh_adapt()
+            sg = eng.mh_sigmas()
+            eng.mh_run(n2, thin=1)
+            t2 = eng.mh_trace()
+            mom = eng.mh_moments()
+            out.append((t1, sg, t2, mom, eng.rhat()))
+    (a1, asg, a2, am, ar), (b1, bsg, b2, bm, br) = out
+    for x, y in zip(a1 + a2, b1 + b2):
+        assert np.array_equal(x, y)
+    assert np.array_equal(asg, bsg)
+    for key in ("mean", "var", "naccept", "accept", "lnPr", "theta"):
+        assert np.array_equal(am[key], bm[key]), key
+    assert np.array_equal(ar, br)
+
+
+def test_sed_reference_correlated_stage():
+    """newMCMC(noCorrelations=False) + 300 Cholesky-correlated steps of the reference's own
+    two-component chain (sed_g3 'm2n_block'), draw for draw."""
+    from mcmc_amd import Engine
+    g2, g3 = load("sed_g2.npz"), load("sed_g3.npz")
+    name = "m2n_block"
+    di = int(g3[name + "__dataset"])
+    nbd = int(g2["nb"][di])
+    with Engine() as eng:
+        eng.sed_load("M2N", g2["nb"][di:di + 1], g2["nu"][di:di + 1], g2["d"][di:di + 1],
+                     g2["sig"][di:di + 1])
+        ref_s = g3[name + "__corr_samples"]
+        eng.mh_init_problem("sed", 1, ref_s[0], g3[name + "__new_sigmas"], param_blocks=np.arange(6),
+                            randomize_start=False)
+        eng.mh_set_sqrt_matrix(g3[name + "__new_sqrt"], rotate=False)
+        k0 = int(g3[name + "__new_kend"])
+        zn = g3[name + "__all_normals"][k0:k0 + 300, None, :]
+        zu = g3[name + "__all_uniforms"][k0:k0 + 300, None]
+        eng.mh_run(300, thin=1, inj_normals=np.ascontiguousarray(zn), inj_uniforms=np.ascontiguousarray(zu))
+        s, l, a = eng.mh_trace()
+    assert nbd > 0
+    assert np.array_equal(a[:, 0, 0], g3[name + "__corr_accepted"][1:])
+    np.testing.assert_allclose(s[:, 0, 0], ref_s[1:], rtol=RTOL)
+    np.testing.assert_allclose(l[:, 0, 0], g3[name + "__corr_lnPr"][1:], rtol=RTOL)
+
+
+@pytest.mark.parametrize("mode", ["uncorr_block", "corr_all", "rotate_block"])
+def test_cl_free_running_philox_equals_oracle(mode):
+    """Free-running device chains (Philox draws) against the oracle driven by the restated
+    Philox streams: pins the stream layout of every proposal mode."""
+    from oracle import refcl as RC
+    from oracle import refcpu as R
+    from mcmc_amd import Engine
+    model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.0, beam=0.0, lmax=700, seed=5)
+    P, C, nsteps, seed = model.nparam, 5, 60, 4321
+    rng = np.random.default_rng(8)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    sig = np.full(P, 0.03)
+    block = mode != "corr_all"
+    with Engine(seed=seed) as eng:
+        eng.cl_load([d])
+        eng.cl_set_binning(model.bins, model.shapefun)
+        eng.mh_init_problem("cl", C, truth, sig, param_blocks=np.arange(P) if block else None,
+                            randomize_start=False)
+        if mode != "uncorr_block":
+            eng.mh_set_sqrt_matrix(L, rotate=(mode == "rotate_block"))
+        eng.mh_run(nsteps, thin=1)
+        s, l, a = eng.mh_trace()
+    npn = 1 if block else (P + 1) & ~1
+    pb = RC.cl_problem(model, [d])
+    for c in (0, 3):
+        draws = R.PhiloxDraws(seed, c, npn)
+        ch = R.Chain(pb, sig, truth, draws, do_block=block, randomize_start=False)
+        if mode != "uncorr_block":
+            ch.prop.sqrt_matrix = L
+            ch.prop.rotate = mode == "rotate_block"
+        if mode == "uncorr_block":
+            # the reference draws n normals per step and uses offset[block]; the device draws one
+            # normal per step for a single-parameter block: give the oracle that draw in slot `block`
+            class OneDraw(R.PhiloxDraws):
+                def normal(self_, n):
+                    z = super().normal(1)
+                    out = np.zeros(n)
+                    out[(self_.step - 1) % P] = z[0]
+                    return out
+            ch.draws = OneDraw(seed, c, npn)
+        ch.run(nsteps)
+        os_, ol, oa = ch.arrays()
+        assert np.array_equal(a[:, 0, c], oa[1:])
+        np.testing.assert_allclose(s[:, 0, c], os_[1:], rtol=RTOL)
+        np.testing.assert_allclose(l[:, 0, c], ol[1:], rtol=1e-11)
+
+
+def test_stepwise_errors():
+    from mcmc_amd import Engine, Mi355Error
+    with Engine() as eng:
+        with pytest.raises(Mi355Error, match="no binned Cl problem"):
+            eng.cl_npar = 3
+            eng.mh_init_problem("cl", 2, np.ones(3), np.ones(3))
