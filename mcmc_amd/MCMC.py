@@ -22,7 +22,7 @@ class ZeroPriorError(Exception):
 
 
 def _device_like(like):
-    if not hasattr(like, "engine") or not hasattr(like.model, "model_id"):
+    if not hasattr(like, "load_into") or not hasattr(like, "problem_kind"):
         raise NotImplementedError(
             "mcmc_amd.MCMC runs the chain on the GPU and needs a likelihood backed by the HIP "
             "library (SEDLikelihood_*, binnedClLikelihood, NormalizedBeamLikelihood); there is no "
@@ -34,8 +34,16 @@ class MCMC(object):
     """Metropolis sampler.  Reference: MCMC.py:58-434."""
 
     def __init__(self, like, proposal=None, startProposal=None, nMC=0, startParams=None,
-                 doBlock=False, nchains=1, seed=None, keep_trace=True):
+                 doBlock=False, nchains=1, seed=None, keep_trace=True, stepwise=None):
+        """stepwise: None = the fused kernel for SED likelihoods (uncorrelated proposals only),
+        the step-wise engine (any proposal of Proposal.py, covariance tracked on the device) for
+        binnedCl and BeamFit; True forces the step-wise engine for SED too - needed for
+        newMCMC(noCorrelations=False) / rotateParams."""
         self.like = _device_like(like)
+        self.kind = like.problem_kind
+        self.stepwise = (self.kind != "sed") if stepwise is None else bool(stepwise)
+        if self.kind != "sed" and not self.stepwise:
+            raise ValueError("the fused kernel serves SED likelihoods only")
         self.doBlock = doBlock
         self.iBlock = 0
         self.mod = like.model
@@ -63,13 +71,11 @@ class MCMC(object):
         if self._detached:
             raise Mi355Error("this MCMC object handed its device chains to newMCMC()")
         if self._eng is None:
-            from .submmSED.likelihood import catalogue_arrays
-            from .submmSED import model as sed_model
-            eng = Engine(seed=self.seed)
-            nb, nu, dd, sg = catalogue_arrays(self.like.data)
             if len(self.like.data) != 1:
-                raise NotImplementedError("one dataset per sampler (use mcmc_amd.batch for catalogues)")
-            eng.sed_load(self.mod.model_id, nb, nu, dd, sg, consts=sed_model.device_constants())
+                raise NotImplementedError("one dataset per sampler object (the Engine API runs "
+                                          "whole catalogues / map sets in one launch)")
+            eng = Engine(seed=self.seed)
+            self.like.load_into(eng)
             self._eng = eng
         return self._eng
 
@@ -95,8 +101,16 @@ class MCMC(object):
         self.nparams = paramarr.shape[-1]
         blocks = np.asarray(self.like.model.paramBlocks, dtype=np.int32) if self.doBlock else None
         try:
-            eng.mh_init(self.nchains, paramarr, self.prop.sigmas, param_blocks=blocks,
-                        randomize_start=random)
+            if self.stepwise:
+                eng.mh_init_problem(self.kind, self.nchains, paramarr, self.prop.sigmas,
+                                    param_blocks=blocks, randomize_start=random, track_cov=True)
+                if getattr(self.prop, "sqrtMatrix", None) is not None:
+                    eng.mh_set_sqrt_matrix(self.prop.sqrtMatrix, rotate=self.prop.rotateParams)
+            else:
+                if getattr(self.prop, "sqrtMatrix", None) is not None:
+                    raise NotImplementedError("correlated proposals need MCMC(..., stepwise=True)")
+                eng.mh_init(self.nchains, paramarr, self.prop.sigmas, param_blocks=blocks,
+                            randomize_start=random)
         except Mi355Error as e:
             if "ZeroPriorError" in str(e):
                 raise ZeroPriorError(params)
@@ -167,6 +181,16 @@ class MCMC(object):
             raise NotImplementedError("covar() is per chain: use nchains=1")
         if params is None:
             params = list(range(self.nparams))
+        if self.stepwise and self._device_moments_valid(burn, stride) and stdevs is None:
+            # running co-moments of the device chain; normalised, as the reference does, by the
+            # *packaged* stdevs (MCMC.py:321-333)
+            sd = np.asarray(self.like.model.unpackage(self.stdev(burn, stride)), np.float64)
+            cov = self._eng.mh_covar(normalized=False)[0, 0]
+            self.covars = np.zeros((self.nparams, self.nparams))
+            ix = np.ix_(params, params)
+            with np.errstate(all="ignore"):
+                self.covars[ix] = (cov if unNormalized else cov / np.outer(sd, sd))[ix]
+            return self.covars
         means = self.like.model.unpackage(self.mean(burn, stride))
         if stdevs is None:
             stdevs = self.like.model.unpackage(self.stdev(burn, stride))
@@ -184,9 +208,17 @@ class MCMC(object):
         """MCMC.py:343-413: new chain(s) started at the present mean with proposal widths
         fac*stdev (fac = 2.4/sqrt(nparam) by default); this object keeps its trace, the device
         state moves to the new object."""
-        if rotateParams or not noCorrelations:
-            raise NotImplementedError("correlated / rotated proposals are not on the device yet; "
-                                      "pass noCorrelations=True (as submmSED/driver.py:173 does)")
+        correlated = rotateParams or not noCorrelations
+        if correlated and not self.stepwise:
+            raise NotImplementedError(
+                "correlated / rotated proposals run on the step-wise engine: create the sampler "
+                "with MCMC(..., stepwise=True) (sampler() does so when noCorrelations=False), or "
+                "pass noCorrelations=True as submmSED/driver.py:173 does")
+        if correlated and not self._device_moments_valid(burn, stride):
+            raise NotImplementedError("correlated restarts use the device's running covariance: "
+                                      "burn=1, stride=1 (what sampler() passes, MCMC.py:515-520)")
+        if correlated and start_draws is not None:
+            raise NotImplementedError("start_draws is a test hook of the uncorrelated path")
         if doBlock is None:
             doBlock = self.doBlock
         eng = self._engine()
@@ -210,7 +242,12 @@ class MCMC(object):
                 if self.like.model.prior(*th) > 0:
                     break
             blocks = np.asarray(self.like.model.paramBlocks, dtype=np.int32) if doBlock else None
-            eng.mh_init(self.nchains, th, sig, param_blocks=blocks, randomize_start=False)
+            self._reinit(eng, th, sig, blocks, False)
+        elif correlated:
+            eng.mh_adapt_corr(fac, random_restart=random, no_correlations=False, rotate=rotateParams,
+                              do_block=doBlock)
+        elif self.stepwise and self._device_moments_valid(burn, stride):
+            eng.mh_adapt_corr(fac, random_restart=random, no_correlations=True, do_block=doBlock)
         elif self._device_moments_valid(burn, stride) and doBlock == self.doBlock:
             eng.mh_adapt(fac, random_restart=random)
         else:
@@ -223,14 +260,17 @@ class MCMC(object):
                 start = start + z[0].reshape(start.shape) * std
             sig = np.array([self.like.model.package(f * s) for s in np.atleast_2d(std)])
             blocks = np.asarray(self.like.model.paramBlocks, dtype=np.int32) if doBlock else None
-            eng.mh_init(self.nchains, np.atleast_2d(start)[None], sig[None], param_blocks=blocks,
-                        randomize_start=True)
+            self._reinit(eng, np.atleast_2d(start)[None], sig[None], blocks, True)
         self._detached = True
         new._eng, new._detached = eng, False
         mom = new._refresh_counts()
         sig = eng_sigmas(eng)
-        new.prop.setSigmas(sig[0, 0] if self.nchains == 1 else sig[0, 0])
+        new.prop.setSigmas(self.like.model.package(sig[0, 0]))
         new.prop.sigmas_all = sig[0]
+        if correlated:
+            Ls = eng.mh_sqrt_matrix()[0]
+            new.prop.sqrtMatrix = Ls[0] if self.nchains == 1 else Ls
+            new.prop.rotateParams = rotateParams
         th0 = mom["theta"][0]
         new.samples = th0[None, 0] if self.nchains == 1 else th0[None]
         new.lnPr = mom["lnPr"][0, :1].copy() if self.nchains == 1 else mom["lnPr"][0][None]
@@ -239,6 +279,13 @@ class MCMC(object):
         if nMC is not None:
             new.MC_append(nMC)
         return new
+
+    def _reinit(self, eng, theta, sigma, blocks, randomize):
+        if self.stepwise:
+            eng.mh_init_problem(self.kind, self.nchains, theta, sigma, param_blocks=blocks,
+                                randomize_start=randomize, track_cov=True)
+        else:
+            eng.mh_init(self.nchains, theta, sigma, param_blocks=blocks, randomize_start=randomize)
 
     def copyMCMC(self):                                   # MCMC.py:415-423
         new = MCMC(self.like, doBlock=self.doBlock, nchains=self.nchains)
@@ -303,7 +350,7 @@ def sampler(like, nMC, prop_sigmas, start_params, plotter=None, fac=None, noCorr
     for isamp, nMC1 in enumerate(nMC):
         if isamp == 0:
             new_s = MCMC(like, startProposal=prop_sigmas, nMC=0, startParams=None, doBlock=doBlock,
-                         seed=seed)
+                         seed=seed, stepwise=True if not noCorrelations else None)
             if inject is None:
                 new_s.setStart(start_params)
             else:                                   # randomise the start with the injected rows

@@ -44,11 +44,17 @@ class _SEDLikelihood(Likelihood.Likelihood):
         super().setmodel_class(model)
         self._eng = None
 
+    problem_kind = "sed"
+
+    def load_into(self, eng):
+        """load this likelihood's data sets as the SED catalogue of `eng`"""
+        nb, nu, dd, sg = catalogue_arrays(self.data)
+        eng.sed_load(self.model.model_id, nb, nu, dd, sg, consts=_model.device_constants())
+
     def engine(self):
         if self._eng is None:
             eng = Engine()
-            nb, nu, dd, sg = catalogue_arrays(self.data)
-            eng.sed_load(self.model.model_id, nb, nu, dd, sg, consts=_model.device_constants())
+            self.load_into(eng)
             self._eng = eng
         return self._eng
 
