@@ -85,22 +85,39 @@ static FormPlan plan_for(const ClData* d) {
   return f;
 }
 
-template <int RT>
-static int launch_form_rt(mi355_ctx* c, const ClFormArgs& a, int64_t rows) {
+static size_t form_lds_bytes(int nbp, int TR) {
+  return (static_cast<size_t>(nbp) * TR + 4 * TR * 3) * sizeof(double) + 2 * TR * sizeof(int);
+}
+
+template <int RT, int CG, int NT>
+static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
   constexpr int TR = 16 * RT;
   const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
-  const size_t lds = (static_cast<size_t>(a.nbp) * TR + 4 * TR * 3) * sizeof(double);
-  static size_t opted[3] = {0, 0, 0};   // largest dynamic LDS opted in per instantiation
-  constexpr int slot = RT == 4 ? 2 : (RT == 2 ? 1 : 0);
-  if (lds > 48 * 1024 && lds > opted[slot]) {
-    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT>),
+  const size_t lds = form_lds_bytes(a.nbp, TR);
+  static size_t opted = 0;              // largest dynamic LDS opted in for this instantiation
+  if (lds > 48 * 1024 && lds > opted) {
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    opted[slot] = lds;
+    opted = lds;
   }
-  const unsigned grid = static_cast<unsigned>(ceil_div64(rows, rows_used));
-  hipLaunchKernelGGL(k_cl_form<RT>, dim3(grid), dim3(256), lds, c->stream, a);
+  const unsigned grid = static_cast<unsigned>(ceil_div64(a.rows, rows_used));
+  hipLaunchKernelGGL((k_cl_form<RT, CG, NT>), dim3(grid), dim3(256), lds, c->stream, a);
   MI355_HIP(hipGetLastError());
   return 0;
+}
+
+template <int RT, int NT>
+static int launch_form_cg(mi355_ctx* c, const ClFormArgs& a) {
+  const int per_wave = ((a.nbp >> 4) + 3) / 4;      // column tiles per wave
+  if (per_wave <= 1) return launch_form<RT, 1, NT>(c, a);
+  if (per_wave == 2) return launch_form<RT, 2, NT>(c, a);
+  return launch_form<RT, 4, NT>(c, a);
+}
+
+template <int RT>
+static int launch_form_rt(mi355_ctx* c, const ClFormArgs& a) {
+  if (a.mode == CL_ROWS_TRIPLE) return launch_form_cg<RT, 3>(c, a);
+  return launch_form_cg<RT, 1>(c, a);
 }
 
 constexpr size_t kClLdsBudget = 144 * 1024;   // of the 160 KB per CU
@@ -134,15 +151,15 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
     MI355_HIP(hipGetLastError());
     return 0;
   }
-  auto fits = [&](int TR) {
-    return (static_cast<size_t>(a.nbp) * TR + 4 * TR * 3) * sizeof(double) <= kClLdsBudget;
-  };
+  MI355_REQUIRE(a.rows < (int64_t{1} << 31), "too many rows (%lld) for one Cl launch",
+                static_cast<long long>(a.rows));
+  auto fits = [&](int TR) { return form_lds_bytes(a.nbp, TR) <= kClLdsBudget; };
   MI355_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
   // the widest row tile that fits in LDS and still leaves >= 2 blocks per CU's worth of work
-  if (fits(64) && a.rows >= 64 * 512) rc = launch_form_rt<4>(c, a, a.rows);
-  else if (fits(32) && a.rows >= 32 * 512) rc = launch_form_rt<2>(c, a, a.rows);
-  else if (fits(16)) rc = launch_form_rt<1>(c, a, a.rows);
+  if (fits(64) && a.rows >= 64 * 512 && a.mode != CL_ROWS_TRIPLE) rc = launch_form_rt<4>(c, a);
+  else if (fits(32) && a.rows >= 32 * 512) rc = launch_form_rt<2>(c, a);
+  else if (fits(16)) rc = launch_form_rt<1>(c, a);
   else {
     set_error("num_points=%d too large for the LDS row tile of the Cl quadratic form", d->nb);
     return -1;

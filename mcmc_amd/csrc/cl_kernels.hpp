@@ -42,34 +42,39 @@ struct ClFormArgs {
   double* out;             // MARGE: chisq[rows]; TRIPLE: G[n][9]
 };
 
-// Value of element `k` (band) of row `grow`: the vector the quadratic form is taken of.
-__device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int64_t grow, int k) {
-  if (grow >= a.rows || k >= a.nb) return 0.0;
-  if (a.mode == CL_ROWS_RAW) return a.bp[static_cast<int64_t>(k) * a.n + grow];   // getquadform(vec)
+// (chain, sub-index) of global row `grow`: sub = marginalisation point (MARGE), row type
+// (TRIPLE) or 0 (RAW, where "chain" is the row itself); chain = -1 for rows past the end.
+__device__ __forceinline__ void cl_row_decode(const ClFormArgs& a, int64_t grow, int& c, int& sub) {
+  if (grow >= a.rows) { c = -1; sub = 0; return; }
+  const int per = (a.mode == CL_ROWS_TRIPLE) ? 3 : (a.mode == CL_ROWS_RAW ? 1 : a.ncal * a.nbeam);
+  const int64_t cc = grow / per;
+  c = static_cast<int>(cc);
+  sub = static_cast<int>(grow - cc * per);
+}
+
+// Value of element `k` (band) of the row (c, sub): the vector the quadratic form is taken of.
+__device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int sub, int k) {
+  if (c < 0 || k >= a.nb) return 0.0;
+  const double bp = a.bp[static_cast<int64_t>(k) * a.n + c];
+  if (a.mode == CL_ROWS_RAW) return bp;                    // getquadform(vec)
   if (a.mode == CL_ROWS_TRIPLE) {
-    const int64_t c = grow / 3;
-    const int t = static_cast<int>(grow - 3 * c);
-    const double bp = a.bp[static_cast<int64_t>(k) * a.n + c];
-    if (t == 0) return a.obs[k] - bp;                    // getdelta without x-factors, :396
-    if (t == 1) return bp;                               // :289
-    return a.beam_uncertain ? a.beam_err[k] * bp : 0.0;  // :293
+    if (sub == 0) return a.obs[k] - bp;                    // getdelta without x-factors, :396
+    if (sub == 1) return bp;                               // :289
+    return a.beam_uncertain ? a.beam_err[k] * bp : 0.0;    // :293
   }
-  const int npc = a.ncal * a.nbeam;
-  const int64_t c = grow / npc;
-  const int m = static_cast<int>(grow - c * npc);
-  double v = a.bp[static_cast<int64_t>(k) * a.n + c];
-  if (a.nbeam > 1) {                                     // :333-334
-    const int ib = m / a.ncal - kClHalfSteps;
+  double v = bp;
+  if (a.nbeam > 1) {                                       // :333-334
+    const int ib = sub / a.ncal - kClHalfSteps;
     v *= 1.0 + a.beam_err[k] * ib * 3 / kClHalfSteps;
   }
-  if (a.ncal > 1) {                                      // :337-338
-    const int ic = m % a.ncal - kClHalfSteps;
+  if (a.ncal > 1) {                                        // :337-338
+    const int ic = sub % a.ncal - kClHalfSteps;
     const double calib = 1.0 + a.calib * ic * 3 / kClHalfSteps;
     v = calib * v;
   }
-  if (a.has_x && a.hasx[k]) {                            // :383-392
+  if (a.has_x && a.hasx[k]) {                              // :383-392
     double zth = v + a.xf[k];
-    if (zth <= 0.0) zth = 0.0;                           // forces -inf rather than NaN, :389
+    if (zth <= 0.0) zth = 0.0;                             // forces -inf rather than NaN, :389
     return a.obs[k] - log(zth);
   }
   return a.obs[k] - v;
@@ -77,71 +82,102 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int64_t grow
 
 // Full-covariance forms on the FP64 matrix cores.  256 threads = 4 waves; the block owns
 // TR = 16*RT rows (all waves share them) and every wave owns the column tiles ct = w, w+4, ...
-// of Y = V.N^-1.  V is staged band-major in LDS (vt[k][TR]); N^-1 fragments come straight from
-// L2 (the matrix is shared by every block).  MFMA operand maps (cdna_hip_programming.md sect. 3):
-// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4*reg.
-template <int RT>
-__global__ __launch_bounds__(256) void k_cl_form(ClFormArgs a) {
+// of Y = V.N^-1, CG of them per pass.  V is staged band-major in LDS (vt[k][TR]); N^-1
+// fragments come straight from L2 (the matrix is shared by every block) and are fetched one
+// k-step ahead of the MFMAs that use them.  MFMA operand maps (cdna_hip_programming.md
+// sect. 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4*reg.
+// NT = 3 for the TRIPLE mode (three dot products per Y row), 1 otherwise.  waves-per-EU >= 2 in
+// the launch bounds caps the kernel at 256 registers, which makes the compiler keep the MFMA
+// accumulators in VGPRs (no per-iteration VGPR<->AGPR copies).
+template <int RT, int CG, int NT>
+__global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
   constexpr int TR = 16 * RT;
-  constexpr int CG = 4;                       // column tiles per wave per pass
   extern __shared__ double smem[];
-  double* vt = smem;                          // [nbp][TR]
-  double* red = smem + static_cast<size_t>(a.nbp) * TR;   // [4][TR][3]
+  double* vt = smem;                                       // [nbp][TR]
+  double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [4][TR][3]
+  int* rowc = reinterpret_cast<int*>(red + 4 * TR * 3);    // [TR] chain of each row
+  int* rows = rowc + TR;                                   // [TR] sub-index of each row
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
   const int64_t row0 = static_cast<int64_t>(blockIdx.x) * rows_used;
 
+  if (tid < TR) {
+    int c = -1, sub = 0;
+    if (tid < rows_used) cl_row_decode(a, row0 + tid, c, sub);
+    rowc[tid] = c;
+    rows[tid] = sub;
+  }
+  __syncthreads();
   for (int idx = tid; idx < a.nbp * TR; idx += 256) {
-    const int k = idx / TR, r = idx - k * TR;
-    vt[idx] = (r < rows_used) ? cl_row_value(a, row0 + r, k) : 0.0;
+    const int k = idx / TR, r = idx % TR;                  // TR is a power of two
+    vt[idx] = cl_row_value(a, rowc[r], rows[r], k);
   }
   __syncthreads();
 
   const int nct = a.nbp >> 4;
   const int lk = lane >> 4, lc = lane & 15;
-  // per-lane partial row sums: MARGE uses [.][.][0] only
-  double part[RT][4][3];
+  double part[RT][4][NT];                                  // per-lane partial row sums
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[rt][i][0] = part[rt][i][1] = part[rt][i][2] = 0.0;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
+  const size_t kstride = static_cast<size_t>(4) * a.nbp;
   for (int ct0 = w; ct0 < nct; ct0 += 4 * CG) {
     double4_t acc[RT][CG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < CG; ++j) acc[rt][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-    int ctj[CG];
-    bool live[CG];
+    // a column tile past the end is computed as a duplicate of the first one and dropped in the
+    // epilogue: no branch inside the MFMA loop
+    const double* nb_ptr[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
-      live[j] = ct0 + 4 * j < nct;
-      ctj[j] = live[j] ? ct0 + 4 * j : ct0;
+      const int ct = (ct0 + 4 * j < nct) ? ct0 + 4 * j : ct0;
+      nb_ptr[j] = a.ninv + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
     }
-#pragma unroll 2
-    for (int k0 = 0; k0 < a.nbp; k0 += 4) {
-      double av[RT], bv[CG];
-      const double* vrow = vt + (k0 + lk) * TR + lc;
+    const double* va_ptr = vt + lk * TR + lc;
+    // ping-pong operand registers, each set fetched one k-step before the MFMAs that read it;
+    // the scheduling barriers keep the compiler from sinking the fetches next to their use
+    double a0[RT], b0[CG], a1[RT], b1[CG];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) av[rt] = vrow[rt * 16];
-      const double* nrow = a.ninv + static_cast<size_t>(k0 + lk) * a.nbp + lc;
+    for (int rt = 0; rt < RT; ++rt) a0[rt] = va_ptr[rt * 16];
 #pragma unroll
-      for (int j = 0; j < CG; ++j) bv[j] = nrow[ctj[j] * 16];
+    for (int j = 0; j < CG; ++j) b0[j] = nb_ptr[j][0];
+    const int ksteps = a.nbp >> 2;                         // a multiple of 4
+    for (int ks = 0; ks < ksteps; ks += 2) {
+#pragma unroll
+      for (int j = 0; j < CG; ++j) b1[j] = nb_ptr[j][(ks + 1) * kstride];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a1[rt] = va_ptr[(ks + 1) * 4 * TR + rt * 16];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < CG; ++j)
-        if (live[j]) {
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv[j], acc[rt][j], 0, 0, 0);
-        }
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[rt], b0[j], acc[rt][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = (ks + 2 < ksteps) ? ks + 2 : ks;      // the last pair refetches itself
+#pragma unroll
+      for (int j = 0; j < CG; ++j) b0[j] = nb_ptr[j][kn * kstride];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a0[rt] = va_ptr[kn * 4 * TR + rt * 16];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < CG; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[rt], b1[j], acc[rt][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // epilogue: Y[row][col] * V[row'][col] summed over this wave's columns
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
-      if (!live[j]) continue;
-      const int col = ctj[j] * 16 + lc;
-      if (col >= a.nb) continue;               // padded columns: Y there is 0*V (or NaN)
+      const int col = (ct0 + 4 * j) * 16 + lc;
+      if (ct0 + 4 * j >= nct || col >= a.nb) continue;     // duplicate tile / padded column
       const double* vcol = vt + col * TR;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -149,12 +185,11 @@ __global__ __launch_bounds__(256) void k_cl_form(ClFormArgs a) {
         for (int i = 0; i < 4; ++i) {
           const int row = rt * 16 + lk + 4 * i;
           const double y = acc[rt][j][i];
-          if (a.mode == CL_ROWS_TRIPLE) {
+          if constexpr (NT == 3) {
             const int g3 = (row / 3) * 3;
             if (row < rows_used) {
-              part[rt][i][0] = fma(y, vcol[g3 + 0], part[rt][i][0]);
-              part[rt][i][1] = fma(y, vcol[g3 + 1], part[rt][i][1]);
-              part[rt][i][2] = fma(y, vcol[g3 + 2], part[rt][i][2]);
+#pragma unroll
+              for (int t = 0; t < 3; ++t) part[rt][i][t] = fma(y, vcol[g3 + t], part[rt][i][t]);
             }
           } else {
             part[rt][i][0] = fma(y, vcol[row], part[rt][i][0]);
@@ -163,14 +198,13 @@ __global__ __launch_bounds__(256) void k_cl_form(ClFormArgs a) {
     }
   }
   // reduce over the 16 lanes that share (lane>>4), i.e. over columns
-  const int nt = (a.mode == CL_ROWS_TRIPLE) ? 3 : 1;
+  constexpr int nt = NT;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t >= nt) continue;
+      for (int t = 0; t < NT; ++t) {
         double v = part[rt][i][t];
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
@@ -181,16 +215,12 @@ __global__ __launch_bounds__(256) void k_cl_form(ClFormArgs a) {
   __syncthreads();
   for (int idx = tid; idx < rows_used * nt; idx += 256) {
     const int r = idx / nt, t = idx - r * nt;
-    const int64_t grow = row0 + r;
-    if (grow >= a.rows) continue;
+    const int c = rowc[r];
+    if (c < 0) continue;
     const double s = ((red[(0 * TR + r) * 3 + t] + red[(1 * TR + r) * 3 + t]) +
                       red[(2 * TR + r) * 3 + t]) + red[(3 * TR + r) * 3 + t];
-    if (a.mode == CL_ROWS_TRIPLE) {
-      const int64_t c = grow / 3;
-      a.out[c * 9 + (grow - 3 * c) * 3 + t] = s;         // G[c][row type][t]
-    } else {
-      a.out[grow] = s;
-    }
+    if (a.mode == CL_ROWS_TRIPLE) a.out[static_cast<int64_t>(c) * 9 + rows[r] * 3 + t] = s;   // G[c][type][t]
+    else a.out[row0 + r] = s;
   }
 }
 
@@ -204,7 +234,7 @@ __global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
     double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < a.nb; ++k) {
       double v[3];
-      for (int t = 0; t < 3; ++t) v[t] = cl_row_value(a, 3 * i + t, k);
+      for (int t = 0; t < 3; ++t) v[t] = cl_row_value(a, static_cast<int>(i), t, k);
       const double var = a.var[k];
       g[0] += v[0] * v[0] / var;                         // getquadform, :420
       for (int t = 1; t < 3; ++t) {
@@ -216,8 +246,10 @@ __global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
   } else {
     if (i >= a.rows) return;
     double s = 0.0;
+    int c, sub;
+    cl_row_decode(a, i, c, sub);
     for (int k = 0; k < a.nb; ++k) {
-      const double v = cl_row_value(a, i, k);
+      const double v = cl_row_value(a, c, sub, k);
       s += v * v / a.var[k];
     }
     a.out[i] = s;
