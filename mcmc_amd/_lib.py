@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355mcmc.so")
+LIB_PATH = os.environ.get("MI355MCMC_LIB") or os.path.join(_HERE, "libmi355mcmc.so")
 ABI_VERSION = 1
 
 c_double_p = C.POINTER(C.c_double)

@@ -12,7 +12,7 @@ struct ClData {
   int nb = 0, nbp = 0, wl = 0;
   bool has_x = false, has_corr = false, beam_uncertain = false, has_pol = false;
   double calib = 0.0;
-  DevBuf<double> obs, xf, beam_err, ninv, var, window, K, bp0;
+  DevBuf<double> obs, xf, beam_err, bfac, ninv, var, window, K, bp0;
   DevBuf<uint8_t> hasx, inc_pol;
   DevBuf<int32_t> win_min, win_max;
 };
@@ -85,39 +85,41 @@ static FormPlan plan_for(const ClData* d) {
   return f;
 }
 
-static size_t form_lds_bytes(int nbp, int TR) {
-  return (static_cast<size_t>(nbp) * TR + 4 * TR * 3) * sizeof(double) + 2 * TR * sizeof(int);
+static size_t form_lds_bytes(int nbp, int TR, int NW = 8) {
+  return (static_cast<size_t>(nbp) * TR + NW * TR * 3) * sizeof(double) + 2 * TR * sizeof(int);
 }
 
-template <int RT, int CG, int NT>
+template <int RT, int CG, int MODE, int NW>
 static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
   constexpr int TR = 16 * RT;
   const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
-  const size_t lds = form_lds_bytes(a.nbp, TR);
+  const size_t lds = form_lds_bytes(a.nbp, TR, NW);
   static size_t opted = 0;              // largest dynamic LDS opted in for this instantiation
   if (lds > 48 * 1024 && lds > opted) {
-    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, NT>),
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, MODE, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     opted = lds;
   }
   const unsigned grid = static_cast<unsigned>(ceil_div64(a.rows, rows_used));
-  hipLaunchKernelGGL((k_cl_form<RT, CG, NT>), dim3(grid), dim3(256), lds, c->stream, a);
+  hipLaunchKernelGGL((k_cl_form<RT, CG, MODE, NW>), dim3(grid), dim3(64 * NW), lds, c->stream, a);
   MI355_HIP(hipGetLastError());
   return 0;
 }
 
-template <int RT, int NT>
+template <int RT, int MODE>
 static int launch_form_cg(mi355_ctx* c, const ClFormArgs& a) {
-  const int per_wave = ((a.nbp >> 4) + 3) / 4;      // column tiles per wave
-  if (per_wave <= 1) return launch_form<RT, 1, NT>(c, a);
-  if (per_wave == 2) return launch_form<RT, 2, NT>(c, a);
-  return launch_form<RT, 4, NT>(c, a);
+  const int nct = a.nbp >> 4;                       // column tiles, shared out over the waves
+  if (nct <= 4) return launch_form<RT, 1, MODE, 4>(c, a);
+  if (nct <= 8) return launch_form<RT, 1, MODE, 8>(c, a);
+  if (nct <= 16) return launch_form<RT, 2, MODE, 8>(c, a);
+  return launch_form<RT, 4, MODE, 8>(c, a);
 }
 
 template <int RT>
 static int launch_form_rt(mi355_ctx* c, const ClFormArgs& a) {
-  if (a.mode == CL_ROWS_TRIPLE) return launch_form_cg<RT, 3>(c, a);
-  return launch_form_cg<RT, 1>(c, a);
+  if (a.mode == CL_ROWS_TRIPLE) return launch_form_cg<RT, CL_ROWS_TRIPLE>(c, a);
+  if (a.mode == CL_ROWS_RAW) return launch_form_cg<RT, CL_ROWS_RAW>(c, a);
+  return launch_form_cg<RT, CL_ROWS_MARGE>(c, a);
 }
 
 constexpr size_t kClLdsBudget = 144 * 1024;   // of the 160 KB per CU
@@ -134,6 +136,7 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   a.xf = d->xf.p;
   a.hasx = d->hasx.p;
   a.beam_err = d->beam_err.p;
+  a.bfac = d->bfac.p;
   a.ninv = d->ninv.p;
   a.var = d->var.p;
   a.has_x = d->has_x ? 1 : 0;
@@ -271,6 +274,10 @@ int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
     if (upload(c, d->hasx, s.has_xfactor ? s.has_xfactor : zb.data(), nb, nbp)) return -2;
     if (upload(c, d->beam_err, s.beam_err ? s.beam_err : zeros.data(), nb, nbp)) return -2;
     if (upload(c, d->inc_pol, s.inc_pol ? s.inc_pol : zb.data(), nb, nbp)) return -2;
+    if (d->bfac.alloc(static_cast<size_t>(kClGrid) * nbp)) return -2;
+    hipLaunchKernelGGL(k_cl_beam_factors, dim3((kClGrid * nbp + 255) / 256), dim3(256), 0, c->stream, nbp,
+                       d->beam_err.p, d->bfac.p);
+    MI355_HIP(hipGetLastError());
     if (upload(c, d->win_min, s.win_min, nb) || upload(c, d->win_max, s.win_max, nb)) return -2;
     if (upload(c, d->window, s.window, static_cast<size_t>(nb) * 3 * s.win_len)) return -2;
     std::vector<double> pad;   // staging; must outlive the copies below

@@ -31,6 +31,7 @@ struct ClFormArgs {
   const double* xf;        // [nbp] x-factors (0 where none)
   const uint8_t* hasx;     // [nbp]
   const double* beam_err;  // [nbp] (zeros when !beam_uncertain)
+  const double* bfac;      // [11][nbp] beam factors 1 + beam_err*ib*3/5, ib = -5..5 (k_cl_beam_factors)
   const double* ninv;      // [nbp][nbp] zero padded (full covariance) ...
   const double* var;       // ... or [nbp] variances (uncorrelated errors)
   int has_x;               // dataset has_xfactors
@@ -80,25 +81,30 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
   return a.obs[k] - v;
 }
 
-// Full-covariance forms on the FP64 matrix cores.  256 threads = 4 waves; the block owns
+// Full-covariance forms on the FP64 matrix cores.  NW waves per block (4 or 8); the block owns
 // TR = 16*RT rows (all waves share them) and every wave owns the column tiles ct = w, w+4, ...
-// of Y = V.N^-1, CG of them per pass.  V is staged band-major in LDS (vt[k][TR]); N^-1
+// of Y = V.N^-1 -> ct = w, w+NW, ..., CG of them per pass.  Eight waves put two on every SIMD, so
+// the row staging (a long dependent chain per element: ln) and the MFMA stream of one wave fill
+// the stalls of the other.  V is staged band-major in LDS (vt[k][TR]); N^-1
 // fragments come straight from L2 (the matrix is shared by every block) and are fetched one
 // k-step ahead of the MFMAs that use them.  MFMA operand maps (cdna_hip_programming.md
 // sect. 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4*reg.
-// NT = 3 for the TRIPLE mode (three dot products per Y row), 1 otherwise.  waves-per-EU >= 2 in
+// MODE (ClFormMode) is a template parameter so that the row-staging loop is specialised; the
+// TRIPLE mode keeps three dot products per Y row (NT = 3), the others one.  waves-per-EU >= 2 in
 // the launch bounds caps the kernel at 256 registers, which makes the compiler keep the MFMA
 // accumulators in VGPRs (no per-iteration VGPR<->AGPR copies).
-template <int RT, int CG, int NT>
-__global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
+template <int RT, int CG, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
   constexpr int TR = 16 * RT;
+  constexpr int NTHR = 64 * NW;
+  constexpr int NT = (MODE == CL_ROWS_TRIPLE) ? 3 : 1;
   extern __shared__ double smem[];
   double* vt = smem;                                       // [nbp][TR]
-  double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [4][TR][3]
-  int* rowc = reinterpret_cast<int*>(red + 4 * TR * 3);    // [TR] chain of each row
+  double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [NW][TR][3]
+  int* rowc = reinterpret_cast<int*>(red + NW * TR * 3);   // [TR] chain of each row
   int* rows = rowc + TR;                                   // [TR] sub-index of each row
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
+  constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
   const int64_t row0 = static_cast<int64_t>(blockIdx.x) * rows_used;
 
   if (tid < TR) {
@@ -108,9 +114,41 @@ __global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
     rows[tid] = sub;
   }
   __syncthreads();
-  for (int idx = tid; idx < a.nbp * TR; idx += 256) {
-    const int k = idx / TR, r = idx % TR;                  // TR is a power of two
-    vt[idx] = cl_row_value(a, rowc[r], rows[r], k);
+  {
+    // every thread owns one row r for the whole staging loop: the per-row factors are hoisted,
+    // the per-(beam point, band) factors come from the table built at load time
+    const int r = tid % TR;                                // TR is a power of two
+    const int c = rowc[r], sub = rows[r];
+    constexpr bool marge = MODE == CL_ROWS_MARGE;
+    double calib = 1.0;
+    const double* bf = nullptr;
+    if (marge && c >= 0) {
+      if (a.ncal > 1) calib = 1.0 + a.calib * (sub % a.ncal - kClHalfSteps) * 3 / kClHalfSteps;   // :337
+      if (a.nbeam > 1) bf = a.bfac + static_cast<size_t>(sub / a.ncal) * a.nbp;                   // :334
+    }
+    // nbp is a multiple of 16 and the stride divides 16: the trip count is a multiple of 4, and
+    // four independent iterations in flight hide the L2 latency of the operand loads
+#pragma unroll 4
+    for (int k = tid / TR; k < a.nbp; k += NTHR / TR) {
+      // branch-free so that the unrolled iterations interleave (one wave per SIMD: the only
+      // latency hiding there is comes from instruction-level parallelism)
+      const bool live = c >= 0 && k < a.nb;
+      const int64_t cc = c >= 0 ? c : 0;
+      double v;
+      if constexpr (!marge) {
+        v = cl_row_value(a, c, sub, k);
+      } else {
+        double b = a.bp[static_cast<int64_t>(k) * a.n + cc];
+        if (bf) b *= bf[k];
+        if (a.ncal > 1) b = calib * b;                     // :338
+        const bool lx = a.has_x && a.hasx[k];              // :383-392
+        double zth = b + a.xf[k];
+        zth = (zth <= 0.0) ? 0.0 : zth;
+        const double t = lx ? log(zth) : b;
+        v = live ? a.obs[k] - t : 0.0;
+      }
+      vt[k * TR + r] = v;
+    }
   }
   __syncthreads();
 
@@ -125,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
       for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
   const size_t kstride = static_cast<size_t>(4) * a.nbp;
-  for (int ct0 = w; ct0 < nct; ct0 += 4 * CG) {
+  for (int ct0 = w; ct0 < nct; ct0 += NW * CG) {
     double4_t acc[RT][CG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -136,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
     const double* nb_ptr[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
-      const int ct = (ct0 + 4 * j < nct) ? ct0 + 4 * j : ct0;
+      const int ct = (ct0 + NW * j < nct) ? ct0 + NW * j : ct0;
       nb_ptr[j] = a.ninv + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
     }
     const double* va_ptr = vt + lk * TR + lc;
@@ -176,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
     // epilogue: Y[row][col] * V[row'][col] summed over this wave's columns
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
-      const int col = (ct0 + 4 * j) * 16 + lc;
-      if (ct0 + 4 * j >= nct || col >= a.nb) continue;     // duplicate tile / padded column
+      const int col = (ct0 + NW * j) * 16 + lc;
+      if (ct0 + NW * j >= nct || col >= a.nb) continue;     // duplicate tile / padded column
       const double* vcol = vt + col * TR;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -213,13 +251,14 @@ __global__ __launch_bounds__(256, 2) void k_cl_form(ClFormArgs a) {
         if (lc == 0) red[(w * TR + rt * 16 + lk + 4 * i) * 3 + t] = v;
       }
   __syncthreads();
-  for (int idx = tid; idx < rows_used * nt; idx += 256) {
+  for (int idx = tid; idx < rows_used * nt; idx += NTHR) {
     const int r = idx / nt, t = idx - r * nt;
     const int c = rowc[r];
     if (c < 0) continue;
-    const double s = ((red[(0 * TR + r) * 3 + t] + red[(1 * TR + r) * 3 + t]) +
-                      red[(2 * TR + r) * 3 + t]) + red[(3 * TR + r) * 3 + t];
-    if (a.mode == CL_ROWS_TRIPLE) a.out[static_cast<int64_t>(c) * 9 + rows[r] * 3 + t] = s;   // G[c][type][t]
+    double s = red[r * 3 + t];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) s += red[(ww * TR + r) * 3 + t];
+    if constexpr (MODE == CL_ROWS_TRIPLE) a.out[static_cast<int64_t>(c) * 9 + rows[r] * 3 + t] = s;   // G[c][type][t]
     else a.out[row0 + r] = s;
   }
 }
@@ -254,6 +293,14 @@ __global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
     }
     a.out[i] = s;
   }
+}
+
+// 1 + beam_err*ibeam*3/halfsteps for ibeam = -5..5 (ClData_CosmoMC.py:334), once per data set
+__global__ void k_cl_beam_factors(int nbp, const double* __restrict__ beam_err, double* __restrict__ bfac) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kClGrid * nbp) return;
+  const int ib = e / nbp - kClHalfSteps, k = e % nbp;
+  bfac[e] = 1.0 + beam_err[k] * ib * 3 / kClHalfSteps;
 }
 
 // ---- marginalisation and -ln L ------------------------------------------------------------
