@@ -38,7 +38,7 @@ def cpu_baseline(nu, d, sig, seconds=12.0):
     first sources of the same catalogue, timed on one host core."""
     from oracle import refcpu as R
     from mcmc_amd import synth
-    nsrc, done, t_used = 0, 0, 0.0
+    nsrc, done, t_used, ess_sum = 0, 0, 0.0, 0.0
     chunk = 500
     t_end = time.perf_counter() + seconds
     while time.perf_counter() < t_end and nsrc < nu.shape[0]:
@@ -51,7 +51,16 @@ def cpu_baseline(nu, d, sig, seconds=12.0):
             done += chunk
         t_used += time.perf_counter() - t0
         nsrc += 1
+        # same ESS estimator as the GPU line (BDA3 11.5), on this chain thinned to <= 128 rows
+        tr = np.asarray(ch.samples)[1:]
+        tr = tr[::max(1, len(tr) // 100)][:128]
+        if len(tr) >= 4:
+            e = np.array([R.ess_bda3(tr[:, i]) for i in range(tr.shape[1])])
+            if np.any(np.isfinite(e)):
+                ess_sum += float(np.nanmin(e))
+    ess_rate = ess_sum / t_used if t_used > 0 else None
     return {"value": done / t_used, "unit": "evals/s", "cores": 1, "kind": "port",
+            "ess_per_sec": ess_rate,
             "sample": "%d MH steps of oracle/refcpu.py (pure Python+NumPy restatement, one step "
                       "at a time) on the first %d sources of the same catalogue, 1 chain each, "
                       "%.1f s" % (done, nsrc, t_used)}
@@ -66,6 +75,8 @@ def main():
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--inner", type=int, default=200, help="MH steps per chain per launch")
     ap.add_argument("--adapt", type=int, default=400, help="untimed stage-0 steps before newMCMC")
+    ap.add_argument("--ess-steps", type=int, default=2000,
+                    help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -119,6 +130,34 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ESS/s (second half of BASELINE.json's metric): a separately timed run that keeps a thinned
+    # trace (100 rows per chain) in HBM, then the multi-chain BDA3 estimator on the device; per
+    # source the minimum over parameters, summed over sources and (chains being independent) ranks
+    ess_out = {}
+    if args.ess_steps > 0:
+        thin = max(1, args.ess_steps // 100)
+        eng.mh_run(100, thin=1)                               # allocates the trace buffers, untimed
+        barrier()
+        t1 = time.perf_counter()
+        eng.mh_run(args.ess_steps, thin=thin)
+        ess = eng.mh_ess()
+        barrier()
+        t_ess = time.perf_counter() - t1
+        ess_min = np.nanmin(np.where(np.isfinite(ess), ess, np.nan), axis=1)
+        tot = torch.tensor([float(np.nansum(ess_min)), t_ess], dtype=torch.float64, device=device)
+        if world > 1:
+            both = [torch.zeros_like(tot) for _ in range(world)]
+            torch.distributed.all_gather(both, tot)
+            ess_total = float(sum(b[0].item() for b in both))
+            t_ess = float(max(b[1].item() for b in both))
+        else:
+            ess_total = float(tot[0].item())
+        ess_out = {"ess_per_sec": ess_total / t_ess, "ess_steps": args.ess_steps, "ess_thin": thin,
+                   "ess_median_per_source": float(np.nanmedian(ess_min)),
+                   "ess_note": "sum over sources of min-over-parameters ESS (BDA3 11.5 multi-chain "
+                               "estimator on the device, %d chains x %d thinned rows per source per "
+                               "GPU) / wall time of that run incl. the estimator" % (C, args.ess_steps // thin)}
+
     evals_per_launch = float(S) * C * inner                   # per GPU
     total_evals = evals_per_launch * args.steps * world
     value = total_evals / elapsed
@@ -152,6 +191,7 @@ def main():
                              "(profiles/r1_bench_summary.txt), ~0.5% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
     }
+    out.update(ess_out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(nu, d, sig, args.cpu_seconds)
     if rank == 0:

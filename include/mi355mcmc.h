@@ -324,6 +324,12 @@ int mi355_rhat_finish_async(mi355_ctx* ctx, const double* sums_dev, int64_t Ctot
  * within-chain variance is not positive.  Needs no catalogue. */
 int mi355_gelman_rubin(mi355_ctx* ctx, int32_t nchain, int32_t P, const double* means,
                        const double* vars, double* rhat);
+/* Effective sample size per (group, parameter) from the trace kept by the last mi355_mh_run
+ * (4 <= rows <= 128, C <= 256): the multi-chain variogram estimator of Gelman et al., BDA3
+ * sect. 11.5, over the C chains of each source / map.  No counterpart in the reference (it has no
+ * ESS or autocorrelation code); BASELINE.json's metric asks for ESS/s.  ess host [S, P], NaN
+ * where the parameter did not move. */
+int mi355_mh_ess(mi355_ctx* ctx, double* ess);
 /* Single-GPU convenience: all C chains are local.  rhat host [S, P]. */
 int mi355_rhat(mi355_ctx* ctx, double* rhat);
 

@@ -764,6 +764,38 @@ int mi355_gelman_rubin(mi355_ctx* c, int32_t nchain, int32_t P, const double* me
   return 0;
 }
 
+int mi355_mh_ess(mi355_ctx* c, double* ess) {
+  MI355_REQUIRE(c && c->mh_ready && ess, "mi355_mh_ess: bad argument");
+  MI355_REQUIRE(c->nkeep >= 4, "mi355_mh_ess: the last mi355_mh_run kept %lld trace rows (need >= 4: "
+                "run with thin > 0)", static_cast<long long>(c->nkeep));
+  MI355_REQUIRE(c->nkeep <= kEssMaxRows, "mi355_mh_ess: %lld trace rows, limit %d (raise thin)",
+                static_cast<long long>(c->nkeep), kEssMaxRows);
+  MI355_REQUIRE(c->C <= 256, "mi355_mh_ess: at most 256 chains per group (got %d)", c->C);
+  MI355_HIP(hipSetDevice(c->device));
+  const int P = c->mhP;
+  const int64_t n = c->mhS * P;
+  if (c->scratch_a.alloc(static_cast<size_t>(n))) return -2;
+  int nt = 64;
+  while (nt < c->C) nt <<= 1;
+  const size_t lds = (static_cast<size_t>(c->nkeep) * nt + nt) * sizeof(double);
+  static size_t opted = 0;
+  if (lds > 48 * 1024 && lds > opted) {
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ess),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    opted = lds;
+  }
+  MI355_REQUIRE(lds <= 150 * 1024, "mi355_mh_ess: trace tile (%zu B) does not fit in LDS", lds);
+  hipLaunchKernelGGL(k_ess, dim3(static_cast<unsigned>(n)), dim3(nt), lds, c->stream, P, c->mhS, c->C,
+                     c->N, static_cast<int>(c->nkeep), c->tr_theta.p, c->scratch_a.p);
+  MI355_HIP(hipGetLastError());
+  std::vector<double> h(static_cast<size_t>(n));
+  MI355_HIP(hipMemcpyAsync(h.data(), c->scratch_a.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  for (int p = 0; p < P; ++p)
+    for (int64_t s = 0; s < c->mhS; ++s) ess[s * P + p] = h[p * c->mhS + s];
+  return 0;
+}
+
 int mi355_rhat(mi355_ctx* c, double* rhat) {
   MI355_REQUIRE(c && c->mh_ready && rhat, "mi355_rhat: bad argument");
   const int64_t n = c->mhS * c->mhP;

@@ -479,6 +479,78 @@ __global__ void k_gelman_rubin(int nchain, int P, const double* __restrict__ mea
   rhat[p] = (within > 0.0) ? sqrt((within + between) / within) : __builtin_nan("");
 }
 
+// ---- effective sample size (no counterpart in the reference: BASELINE.json asks for ESS/s) ----
+// Multi-chain estimator of Gelman et al., BDA3 sect. 11.5, on the trace of the last run:
+//   n_eff = m n / (1 + 2 sum_t rho_t),  rho_t = 1 - V_t / (2 var+),
+//   V_t = sum_j sum_i (x_ij - x_(i-t)j)^2 / (m (n - t)),  var+ = (n-1)/n W + B/n,
+// the sum running over t = 1, 2, ... until rho_(t+1) + rho_(t+2) < 0 at an odd t (or the lags
+// run out).  One block per (group, parameter); thread j owns chain j (C <= blockDim.x) and keeps
+// its n <= kEssMaxRows trace values in LDS.
+constexpr int kEssMaxRows = 128;
+
+__global__ __launch_bounds__(256) void k_ess(int P, int64_t S, int C, int64_t N, int nrows,
+                                             const double* __restrict__ trace /*[nrows][P][N]*/,
+                                             double* __restrict__ ess /*[P][S]*/) {
+  extern __shared__ double sh[];                       // [nrows][blockDim.x] + reduction scratch
+  const int64_t s = blockIdx.x / P;
+  const int p = static_cast<int>(blockIdx.x % P);
+  const int j = threadIdx.x, nt = blockDim.x;
+  double* x = sh;
+  double* red = sh + static_cast<size_t>(nrows) * nt;
+  const bool live = j < C;
+  double sum = 0.0;
+  for (int i = 0; i < nrows; ++i) {
+    const double v = live ? trace[(static_cast<int64_t>(i) * P + p) * N + s * C + j] : 0.0;
+    x[i * nt + j] = v;
+    sum += v;
+  }
+  const double mean_j = sum / nrows;
+  double ss = 0.0;
+  for (int i = 0; i < nrows; ++i) {
+    const double dlt = x[i * nt + j] - mean_j;
+    ss += dlt * dlt;
+  }
+  auto block_sum = [&](double v) -> double {
+    __syncthreads();
+    red[j] = live ? v : 0.0;
+    __syncthreads();
+    for (int off = nt >> 1; off > 0; off >>= 1) {
+      if (j < off) red[j] += red[j + off];
+      __syncthreads();
+    }
+    return red[0];
+  };
+  const double m = static_cast<double>(C), n = static_cast<double>(nrows);
+  const double W = block_sum(ss / (n - 1.0)) / m;                  // mean within-chain variance
+  const double gmean = block_sum(mean_j) / m;
+  const double dm = mean_j - gmean;
+  const double B_over_n = (C > 1) ? block_sum(dm * dm) / (m - 1.0) : 0.0;
+  const double varplus = (n - 1.0) / n * W + B_over_n;
+  double rho_sum = 0.0, prev = 0.0;
+  bool have_prev = false;
+  if (varplus > 0.0) {
+    for (int t = 1; t < nrows; ++t) {
+      double v = 0.0;
+      for (int i = t; i < nrows; ++i) {
+        const double dlt = x[i * nt + j] - x[(i - t) * nt + j];
+        v += dlt * dlt;
+      }
+      const double Vt = block_sum(v) / (m * (n - t));
+      const double rho = 1.0 - Vt / (2.0 * varplus);
+      // pairs (rho_1, rho_2), (rho_3, rho_4), ...: stop at the first pair with a negative sum
+      if (!have_prev) {
+        prev = rho;
+        have_prev = true;
+      } else {
+        if (prev + rho < 0.0) break;
+        rho_sum += prev + rho;
+        have_prev = false;
+      }
+    }
+  }
+  if (j == 0) ess[p * S + s] = (varplus > 0.0) ? m * n / (1.0 + 2.0 * rho_sum) : __builtin_nan("");
+}
+
 __global__ void k_scale(int64_t n, double f, double* x) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= f;

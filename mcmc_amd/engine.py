@@ -526,6 +526,12 @@ class Engine:
         check(self.lib.mi355_rhat(self._h, _dp(out)))
         return out
 
+    def mh_ess(self):
+        """Effective sample size [S, P] from the trace of the last mh_run (BDA3 11.5)."""
+        out = np.empty((self.S, self.P))
+        check(self.lib.mi355_mh_ess(self._h, _dp(out)))
+        return out
+
     def gelman_rubin(self, means, variances):
         means = _f64(means)
         variances = _f64(variances, means.shape)

@@ -229,3 +229,25 @@ def test_free_running_chains_match_oracle(eng, mid, do_block):
             np.testing.assert_allclose(tr_s[:, s, c], os_[1:], rtol=1e-12)
             np.testing.assert_allclose(tr_l[:, s, c], ol[1:], rtol=1e-12)
             assert mom["naccept"][s, c] == ch.naccept
+
+
+def test_ess_matches_bda3_restatement():
+    """mi355_mh_ess (no reference counterpart: BASELINE.json's ESS/s) against the numpy
+    restatement of the same estimator on the same trace."""
+    from mcmc_amd import Engine, synth
+    S, C = 6, 64
+    nu, d, sig, _ = synth.sed_catalogue(S, seed=21)
+    with Engine(seed=77) as eng:
+        eng.sed_load("M2N", np.full(S, 8, np.int32), nu, d, sig)
+        eng.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6))
+        eng.mh_run(600)
+        eng.mh_adapt()
+        eng.mh_run(1200, thin=12)
+        tr, _, _ = eng.mh_trace()                       # [100, S, C, 6]
+        ess = eng.mh_ess()
+    assert ess.shape == (S, 6)
+    for s in range(S):
+        for p in range(6):
+            ref = R.ess_bda3(tr[:, s, :, p])
+            assert abs(ess[s, p] - ref) <= 1e-9 * abs(ref), (s, p, ess[s, p], ref)
+    assert np.all(ess > 1.0) and np.all(ess <= 100 * C * 1.5)
