@@ -120,7 +120,10 @@ struct LaunchRun {
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
     MI355_HIP(hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k_mh_run<M>, dim3(grid), dim3(bs), lds, c->stream, a);
+    if (c->kc.fast_ok != 0.0)
+      hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
     MI355_HIP(hipGetLastError());
     MI355_HIP(hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
@@ -292,7 +295,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     *lo = static_cast<double>(l - static_cast<long double>(*hi));
   };
   c->kc = SedConsts{m->h_over_k, m->nu_b, m->prefac, m->Tmin, m->Tmax, m->bmin, m->bmax,
-                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0};
+                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0, 0.0};
   dd_log(m->nu_b, &c->kc.ln_nub_hi, &c->kc.ln_nub_lo);
   const bool base_is_nu = (m->model == MI355_SED_M1 || m->model == MI355_SED_M2);
   // host-side derived band fields (each rounded once, as the reference computes them)
@@ -316,6 +319,24 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
                       "source %lld band %d: frequency %g GHz out of range",
                       static_cast<long long>(s), j, v);
     }
+  }
+  // The fast kernels run without argument clamps: allow them only if, over the whole prior box,
+  // every Planck argument h nu/kT and every power-law exponent (3+beta) ln(base) stays below 300
+  // (products of two such exponentials still fit a double); otherwise the exact OCML path runs.
+  {
+    const double emax = std::fmax(std::fabs(3.0 + m->bmin), std::fabs(3.0 + m->bmax));
+    bool ok = m->Tmin > 0.0 && std::isfinite(m->bmin) && std::isfinite(m->bmax) &&
+              c->kc.hk_nub / m->Tmin < 300.0 &&
+              std::fmax(std::fabs(m->bmin), std::fabs(m->bmax)) * std::fabs(c->kc.ln_nub_hi) < 300.0;
+    for (int64_t s = 0; s < S && ok; ++s)
+      for (int j = 0; j < nb[s]; ++j) {
+        const double* o = h.data() + s * stride;
+        if (!(o[1 * nb_max + j] / m->Tmin < 300.0) || !(emax * std::fabs(o[5 * nb_max + j]) < 300.0)) {
+          ok = false;
+          break;
+        }
+      }
+    c->kc.fast_ok = ok ? 1.0 : 0.0;
   }
   if (c->bands.alloc(h.size())) return -2;
   if (c->nb.alloc(static_cast<size_t>(S))) return -2;

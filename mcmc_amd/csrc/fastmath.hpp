@@ -45,30 +45,35 @@ __device__ __forceinline__ double reduce_ln2(double x, double extra, int& n) {
   return r + extra;
 }
 
-// e^(x + extra) for x in [-kExpMax, kExpMax] (clamped), |extra| << 1.
+// e^(x + extra) for x in [-kExpMax, kExpMax] (clamped), |extra| << 1.  CLAMP = false is for
+// callers that have bounded |x| themselves (mi355_sed_load checks the catalogue against the prior
+// box, see SedConsts::fast_ok): two instructions fewer per call.
+template <bool CLAMP = true>
 __device__ __forceinline__ double exp_dd(double x, double extra) {
-  x = fmin(fmax(x, -kExpMax), kExpMax);
+  if (CLAMP) x = fmin(fmax(x, -kExpMax), kExpMax);
   int n;
   const double r = reduce_ln2(x, extra, n);
   return ldexp(1.0 + expm1_reduced(r), n);
 }
 
-__device__ __forceinline__ double exp_fast(double x) { return exp_dd(x, 0.0); }
+__device__ __forceinline__ double exp_fast(double x) { return exp_dd<true>(x, 0.0); }
 
 // base^e with ln(base) = lhi + llo known to double-double precision.
+template <bool CLAMP = true>
 __device__ __forceinline__ double pow_prelog(double e, double lhi, double llo) {
   const double p = e * lhi;
   const double pe = fma(e, lhi, -p);       // exact low part of the product
-  return exp_dd(p, fma(e, llo, pe));
+  return exp_dd<CLAMP>(p, fma(e, llo, pe));
 }
 
-__device__ __forceinline__ double exp10_fast(double x) { return pow_prelog(x, kLn10Hi, kLn10Lo); }
+__device__ __forceinline__ double exp10_fast(double x) { return pow_prelog<true>(x, kLn10Hi, kLn10Lo); }
 
 // expm1(x), any finite x (clamped to [-40, kExpMax]: below -40 the result is -1 to the last bit):
 //   2^n (1+q) - 1 = 2^n * (q + (1 - 2^-n)),  q = expm1(r); the inner sum is exact-ish (one
 //   rounding), so there is no cancellation for any n.
+template <bool CLAMP = true>
 __device__ __forceinline__ double expm1_fast(double x) {
-  x = fmin(fmax(x, -40.0), kExpMax);
+  if (CLAMP) x = fmin(fmax(x, -40.0), kExpMax);
   int n;
   const double r = reduce_ln2(x, 0.0, n);
   const double q = expm1_reduced(r);
@@ -79,11 +84,11 @@ __device__ __forceinline__ double expm1_fast(double x) {
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.
+// 1/b to ~2^-50: v_rcp_f64 (about 2^-26) plus ONE Newton-Raphson step.  That is all the residual
+// correction in div_rcp needs: its result errs by |q| * eps_r^2 before the final rounding.
 __device__ __forceinline__ double rcp_nr(double b) {
   double r = __builtin_amdgcn_rcp(b);
-  double e = fma(-b, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-b, r, 1.0);
+  const double e = fma(-b, r, 1.0);
   r = fma(r, e, r);
   return r;
 }
@@ -95,5 +100,63 @@ __device__ __forceinline__ double div_rcp(double a, double b, double rb) {   // 
 }
 
 __device__ __forceinline__ double div_fast(double a, double b) { return div_rcp(a, b, rcp_nr(b)); }
+
+// ---- Box-Muller kernels ------------------------------------------------------------------------
+// ln(u) for normal positive u (the Box-Muller radius only needs a few ulp): u = m 2^e with
+// m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), ln m = 2s + s z (2/3 + 2/5 z + ... ) with z = s^2.
+__device__ __forceinline__ double log_fast(double u) {
+  int e = __builtin_amdgcn_frexp_exp(u);
+  double m = __builtin_amdgcn_frexp_mant(u);               // [0.5, 1)
+  const bool lo = m < 0x1.6a09e667f3bcdp-1;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = div_fast(f, 2.0 + f);
+  const double z = s * s;
+  double r = 2.0 / 23.0;
+  r = fma(r, z, 2.0 / 21.0);
+  r = fma(r, z, 2.0 / 19.0);
+  r = fma(r, z, 2.0 / 17.0);
+  r = fma(r, z, 2.0 / 15.0);
+  r = fma(r, z, 2.0 / 13.0);
+  r = fma(r, z, 2.0 / 11.0);
+  r = fma(r, z, 2.0 / 9.0);
+  r = fma(r, z, 2.0 / 7.0);
+  r = fma(r, z, 2.0 / 5.0);
+  r = fma(r, z, 2.0 / 3.0);
+  const double lm = fma(s * z, r, s + s);
+  const double fe = static_cast<double>(e);
+  return fma(fe, kLn2Hi, fma(fe, kLn2Lo, lm));
+}
+
+// sin(2 pi u), cos(2 pi u) for u in [0, 1): quarter-turn reduction (exact), then the fdlibm
+// kernel polynomials on |y| <= pi/4 (error < 2^-57) and a quadrant rotation by selects.
+__device__ __forceinline__ void sincos2pi_fast(double u, double* sn, double* cs) {
+  const double a = 4.0 * u;
+  const double fq = rint(a);
+  const double f = a - fq;                                  // exact, |f| <= 1/2
+  const int q = static_cast<int>(fq) & 3;
+  const double y = fma(f, 0x1.1a62633145c07p-54, f * 0x1.921fb54442d18p+0);   // f * pi/2
+  const double z = y * y;
+  double rs = 1.58969099521155010221e-10;
+  rs = fma(rs, z, -2.50507602534068634195e-08);
+  rs = fma(rs, z, 2.75573137070700676789e-06);
+  rs = fma(rs, z, -1.98412698298579493134e-04);
+  rs = fma(rs, z, 8.33333333332248946124e-03);
+  rs = fma(rs, z, -1.66666666666666324348e-01);
+  const double s0 = fma(y * z, rs, y);
+  double rc = -1.13596475577881948265e-11;
+  rc = fma(rc, z, 2.08757232129817482790e-09);
+  rc = fma(rc, z, -2.75573143513906633035e-07);
+  rc = fma(rc, z, 2.48015872894767294178e-05);
+  rc = fma(rc, z, -1.38888888888741095749e-03);
+  rc = fma(rc, z, 4.16666666666666019037e-02);
+  const double c0 = fma(z * z, rc, fma(-0.5, z, 1.0));
+  // angle = y + q pi/2
+  const double sa = (q & 1) ? c0 : s0;
+  const double ca = (q & 1) ? s0 : c0;
+  *sn = (q & 2) ? -sa : sa;
+  *cs = ((q + 1) & 2) ? -ca : ca;
+}
 
 }  // namespace mi355

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
     if (!(lnalpha >= 0.0)) {
       const double u = a.inj_u ? a.inj_u[n]
                                : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
-      reject = !(exp(lnalpha) > u);                        // :264
+      reject = !(exp_fast(lnalpha) > u);                   // :264
     }
     accepted = !reject;
   }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   }
   const double lp = accepted ? v : prev;
   const double cnt = static_cast<double>(a.nsamp + 1);
-  const double rn = 1.0 / cnt;
+  const double rn = rcp_nr(cnt);                           // as the fused kernel
   const double cf = 1.0 - rn;
   for (int i = 0; i < P; ++i) {
     double x = a.theta[i * N + n];

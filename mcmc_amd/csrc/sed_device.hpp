@@ -106,7 +106,9 @@ __device__ __forceinline__ bool all_finite(const double* th) {
 // points a Metropolis step can accept): T>=Tmin>0 so every Planck argument is positive, and the
 // power-law bases are launch constants whose logarithms the host precomputed.  Same formulas as
 // the exact path below, transcendental kernels from fastmath.hpp; differences vs the reference
-// stay at the 1e-15 level (tests/test_sed_gpu.py).  THICK keeps the exact path (its power-law
+// stay at the 1e-15 level (tests/test_sed_gpu.py).  The transcendental kernels run without their
+// argument clamps: mi355_sed_load only enables this path (SedConsts::fast_ok) when every band of
+// the catalogue keeps h nu/kT and (3+beta) ln(base) below 300 over the whole prior box.  THICK keeps the exact path (its power-law
 // base depends on the parameter nu0).
 template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands& B,
@@ -117,11 +119,11 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double A = (MODEL == MI355_SED_M1N) ? th[0] : exp10_fast(th[0]);
     const double T = th[2], e3 = 3.0 + th[1];
     const double rT = 1.0 / T;
-    const double en = expm1_fast(div_rcp(k.hk_nub, T, rT));
+    const double en = expm1_fast<false>(div_rcp(k.hk_nub, T, rT));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pow_prelog(e3, B.lhi(j), B.llo(j)) * en, expm1_fast(x));
+      const double g = div_fast(pow_prelog<false>(e3, B.lhi(j), B.llo(j)) * en, expm1_fast<false>(x));
       const double r = B.d(j) - A * g;
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -133,25 +135,25 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double T1 = th[2], T2 = th[5];
     const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
     const double rT1 = 1.0 / T1, rT2 = 1.0 / T2;
-    const double en1 = expm1_fast(div_rcp(k.hk_nub, T1, rT1));
-    const double en2 = expm1_fast(div_rcp(k.hk_nub, T2, rT2));
+    const double en1 = expm1_fast<false>(div_rcp(k.hk_nub, T1, rT1));
+    const double en2 = expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
-      const double g1 = div_fast(pow_prelog(e1, lh, ll) * en1, expm1_fast(div_rcp(hn, T1, rT1)));
-      const double g2 = div_fast(pow_prelog(e2, lh, ll) * en2, expm1_fast(div_rcp(hn, T2, rT2)));
+      const double g1 = div_fast(pow_prelog<false>(e1, lh, ll) * en1, expm1_fast<false>(div_rcp(hn, T1, rT1)));
+      const double g2 = div_fast(pow_prelog<false>(e2, lh, ll) * en2, expm1_fast<false>(div_rcp(hn, T2, rT2)));
       const double r = B.d(j) - fma(A2, g2, A1 * g1);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
   } else if constexpr (MODEL == MI355_SED_M1) {
     const double T = th[1], e3 = 3.0 + th[0];
-    const double pre = k.prefac * pow_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
+    const double pre = k.prefac * pow_prelog<false>(-th[0], k.ln_nub_hi, k.ln_nub_lo);
     const double rT = 1.0 / T;
     double FNiF = 0.0, FNid = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pre * pow_prelog(e3, B.lhi(j), B.llo(j)), expm1_fast(x));
+      const double g = div_fast(pre * pow_prelog<false>(e3, B.lhi(j), B.llo(j)), expm1_fast<false>(x));
       const double gw = g * B.w(j);
       FNiF = fma(gw, g, FNiF);
       FNid = fma(gw, B.d(j), FNid);
@@ -305,7 +307,7 @@ template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_auto(const double* th, double prior, const Bands& B,
                                                   const SedConsts& k, double* derived) {
   constexpr int P = ModelTraits<MODEL>::P;
-  if (prior > 0.0 && all_finite<P>(th)) return sed_lnlike_fast<MODEL>(th, B, k, derived);
+  if (k.fast_ok != 0.0 && prior > 0.0 && all_finite<P>(th)) return sed_lnlike_fast<MODEL>(th, B, k, derived);
   return sed_lnlike<MODEL>(th, B, k, derived);
 }
 }  // namespace mi355

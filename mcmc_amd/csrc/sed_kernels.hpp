@@ -227,8 +227,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 }
 
 // ---- fused propose / evaluate / accept, nsteps per launch (MCMC.py:225-286) ------------------
-template <int MODEL>
-__global__ __launch_bounds__(kBlockThreads) void k_mh_run(MhArgs a) {
+// FAST: the clamp-free transcendental kernels (catalogue checked at load, SedConsts::fast_ok);
+// otherwise the exact OCML path - a separate instantiation so that it does not cost the fast
+// one registers.
+#ifndef MI355_MH_MIN_WAVES
+#define MI355_MH_MIN_WAVES 2
+#endif
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   constexpr int P = ModelTraits<MODEL>::P;
   extern __shared__ double smem[];
   const int stride = kBandFields * a.nbm;
@@ -301,12 +307,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_run(MhArgs a) {
     bool accepted = false;
     double next = lnPr;
     if (prior > 0.0 && all_finite<P>(nw)) {
-      double v = sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr);
+      double v = FAST ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
+                      : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         if (prior != 1.0) v += log(prior);                 // :250
         const double lnalpha = v - lnPr;                   // :251 (+ lndensityRatio = 0, :252)
-        const bool reject = !(lnalpha >= 0.0) && !(exp(lnalpha) > u);   // :264
+        const bool reject = !(lnalpha >= 0.0) && !(exp_fast(lnalpha) > u);   // :264
         if (!reject) {
           accepted = true;
           next = v;
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_run(MhArgs a) {
     if (a.nblock) blk = (blk + 1 == a.nblock) ? 0 : blk + 1;   // :278-279
 
     // running ddof=0 moments over every appended sample (mean/stdev with burn=1, :290-307)
-    const double rn = 1.0 / static_cast<double>(a.nsamp0 + t + 1);
+    const double rn = rcp_nr(static_cast<double>(a.nsamp0 + t + 1));   // 1/n to 2^-50
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const double dlt = th[i] - mu[i];
