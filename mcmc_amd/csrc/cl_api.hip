@@ -12,7 +12,7 @@ struct ClData {
   int nb = 0, nbp = 0, wl = 0;
   bool has_x = false, has_corr = false, beam_uncertain = false, has_pol = false;
   double calib = 0.0;
-  DevBuf<double> obs, xf, beam_err, bfac, ninv, var, window, K, bp0;
+  DevBuf<double> obs, xf, beam_err, bfac, ninv, nsym, var, window, K, bp0;
   DevBuf<uint8_t> hasx, inc_pol;
   DevBuf<int32_t> win_min, win_max;
 };
@@ -89,19 +89,19 @@ static size_t form_lds_bytes(int nbp, int TR, int NW = 8) {
   return (static_cast<size_t>(nbp) * TR + NW * TR * 3) * sizeof(double) + 2 * TR * sizeof(int);
 }
 
-template <int RT, int CG, int MODE, int NW>
+template <int RT, int CG, int MODE, int NW, bool SYM = false>
 static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
   constexpr int TR = 16 * RT;
   const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
   const size_t lds = form_lds_bytes(a.nbp, TR, NW);
   static size_t opted = 0;              // largest dynamic LDS opted in for this instantiation
   if (lds > 48 * 1024 && lds > opted) {
-    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, MODE, NW>),
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, MODE, NW, SYM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     opted = lds;
   }
   const unsigned grid = static_cast<unsigned>(ceil_div64(a.rows, rows_used));
-  hipLaunchKernelGGL((k_cl_form<RT, CG, MODE, NW>), dim3(grid), dim3(64 * NW), lds, c->stream, a);
+  hipLaunchKernelGGL((k_cl_form<RT, CG, MODE, NW, SYM>), dim3(grid), dim3(64 * NW), lds, c->stream, a);
   MI355_HIP(hipGetLastError());
   return 0;
 }
@@ -109,6 +109,10 @@ static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
 template <int RT, int MODE>
 static int launch_form_cg(mi355_ctx* c, const ClFormArgs& a) {
   const int nct = a.nbp >> 4;                       // column tiles, shared out over the waves
+  if constexpr (MODE != CL_ROWS_TRIPLE) {
+    // diagonal forms: block-upper symmetrised matrix, half the MFMA work, from 8 tiles up
+    if (nct >= 8) return launch_form<RT, 1, MODE, 8, true>(c, a);
+  }
   if (nct <= 4) return launch_form<RT, 1, MODE, 4>(c, a);
   if (nct <= 8) return launch_form<RT, 1, MODE, 8>(c, a);
   if (nct <= 16) return launch_form<RT, 2, MODE, 8>(c, a);
@@ -138,6 +142,7 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   a.beam_err = d->beam_err.p;
   a.bfac = d->bfac.p;
   a.ninv = d->ninv.p;
+  a.nsym = d->nsym.p;
   a.var = d->var.p;
   a.has_x = d->has_x ? 1 : 0;
   a.beam_uncertain = d->beam_uncertain ? 1 : 0;
@@ -280,13 +285,25 @@ int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
     MI355_HIP(hipGetLastError());
     if (upload(c, d->win_min, s.win_min, nb) || upload(c, d->win_max, s.win_max, nb)) return -2;
     if (upload(c, d->window, s.window, static_cast<size_t>(nb) * 3 * s.win_len)) return -2;
-    std::vector<double> pad;   // staging; must outlive the copies below
+    std::vector<double> pad, sym;   // staging; must outlive the copies below
     if (d->has_corr) {
       pad.assign(static_cast<size_t>(nbp) * nbp, 0.0);
       for (int r = 0; r < nb; ++r)
         std::memcpy(&pad[static_cast<size_t>(r) * nbp], s.N_inv + static_cast<size_t>(r) * nb,
                     nb * sizeof(double));
       if (upload(c, d->ninv, pad.data(), pad.size())) return -2;
+      // block-upper symmetrised copy for the diagonal forms (k_cl_form SYM): one rounding per
+      // off-diagonal entry, none at all when N^-1 is exactly symmetric
+      sym.assign(pad.size(), 0.0);
+      for (int r = 0; r < nbp; ++r)
+        for (int q = 0; q < nbp; ++q) {
+          const int I = r >> 4, J = q >> 4;
+          if (I == J) sym[static_cast<size_t>(r) * nbp + q] = pad[static_cast<size_t>(r) * nbp + q];
+          else if (I < J)
+            sym[static_cast<size_t>(r) * nbp + q] =
+                pad[static_cast<size_t>(r) * nbp + q] + pad[static_cast<size_t>(q) * nbp + r];
+        }
+      if (upload(c, d->nsym, sym.data(), sym.size())) return -2;
     } else {
       pad.assign(static_cast<size_t>(nbp), 1.0);
       std::memcpy(pad.data(), s.var, nb * sizeof(double));

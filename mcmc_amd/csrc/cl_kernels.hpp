@@ -33,6 +33,8 @@ struct ClFormArgs {
   const double* beam_err;  // [nbp] (zeros when !beam_uncertain)
   const double* bfac;      // [11][nbp] beam factors 1 + beam_err*ib*3/5, ib = -5..5 (k_cl_beam_factors)
   const double* ninv;      // [nbp][nbp] zero padded (full covariance) ...
+  const double* nsym;      // [nbp][nbp] block-upper symmetrised copy: tile (I,J), I<J, holds
+                           // N_IJ + N_JI^T, diagonal tiles N_II, tiles I>J unused (k_cl_form SYM)
   const double* var;       // ... or [nbp] variances (uncorrelated errors)
   int has_x;               // dataset has_xfactors
   int beam_uncertain;
@@ -93,8 +95,13 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 // TRIPLE mode keeps three dot products per Y row (NT = 3), the others one.  waves-per-EU >= 2 in
 // the launch bounds caps the kernel at 256 registers, which makes the compiler keep the MFMA
 // accumulators in VGPRs (no per-iteration VGPR<->AGPR copies).
-template <int RT, int CG, int MODE, int NW>
+// SYM (diagonal forms v N^-1 v only, CG = 1): the quadratic form is accumulated over the block
+// upper triangle of the symmetrised matrix, sum_J (sum_{I<=J} v_I S_IJ) v_J, which halves the
+// MFMA work; column tiles are dealt to the waves in snake order so that every wave gets the same
+// number of k-steps.
+template <int RT, int CG, int MODE, int NW, bool SYM>
 __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
+  static_assert(!SYM || (CG == 1 && MODE != CL_ROWS_TRIPLE), "SYM needs CG == 1 and a diagonal form");
   constexpr int TR = 16 * RT;
   constexpr int NTHR = 64 * NW;
   constexpr int NT = (MODE == CL_ROWS_TRIPLE) ? 3 : 1;
@@ -163,7 +170,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
       for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
   const size_t kstride = static_cast<size_t>(4) * a.nbp;
-  for (int ct0 = w; ct0 < nct; ct0 += NW * CG) {
+  const double* nmat = SYM ? a.nsym : a.ninv;
+  for (int pass = 0;; ++pass) {
+    int ct0;
+    if (SYM) {
+      const int base = pass * NW;
+      if (base >= nct) break;
+      ct0 = (pass & 1) ? base + NW - 1 - w : base + w;     // snake: long and short tiles pair up
+      if (ct0 >= nct) continue;
+    } else {
+      ct0 = w + pass * NW * CG;
+      if (ct0 >= nct) break;
+    }
     double4_t acc[RT][CG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
       const int ct = (ct0 + NW * j < nct) ? ct0 + NW * j : ct0;
-      nb_ptr[j] = a.ninv + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
+      nb_ptr[j] = nmat + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
     }
     const double* va_ptr = vt + lk * TR + lc;
     // ping-pong operand registers, each set fetched one k-step before the MFMAs that read it;
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
     for (int rt = 0; rt < RT; ++rt) a0[rt] = va_ptr[rt * 16];
 #pragma unroll
     for (int j = 0; j < CG; ++j) b0[j] = nb_ptr[j][0];
-    const int ksteps = a.nbp >> 2;                         // a multiple of 4
+    const int ksteps = SYM ? (ct0 + 1) * 4 : a.nbp >> 2;   // a multiple of 4
     for (int ks = 0; ks < ksteps; ks += 2) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) b1[j] = nb_ptr[j][(ks + 1) * kstride];
