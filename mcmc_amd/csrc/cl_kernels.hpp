@@ -13,8 +13,17 @@
 //   k_cl_combine   : log-sum-exp over the 11 (x11) grid / analytic marginalisation, -chi2/2.
 #pragma once
 #include "common.hpp"
+#include "fastmath.hpp"
 
 namespace mi355 {
+
+// ln for the offset-lognormal deltas in the MFMA kernel's row staging: the library's short
+// branch-free kernel (a few ulp; |delta| errors of ~1e-15 against ln(C+x) ~ 8) with the IEEE end
+// cases the reference relies on (ln 0 = -inf, :389).
+__device__ __forceinline__ double cl_log(double z) {
+  const double l = log_fast(z);
+  return (z > 0.0) ? ((z < __builtin_inf()) ? l : z) : ((z == 0.0) ? -__builtin_inf() : __builtin_nan(""));
+}
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
         const bool lx = a.has_x && a.hasx[k];              // :383-392
         double zth = b + a.xf[k];
         zth = (zth <= 0.0) ? 0.0 : zth;
-        const double t = lx ? log(zth) : b;
+        const double t = lx ? cl_log(zth) : b;
         v = live ? a.obs[k] - t : 0.0;
       }
       vt[k * TR + r] = v;

@@ -383,6 +383,9 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
     case 1: v = expm1_fast(a[i]); break;
     case 2: v = pow_prelog(a[i], b[i], c[i]); break;
     case 3: v = div_fast(a[i], b[i]); break;
+    case 5: v = log_fast(a[i]); break;
+    case 6: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = sn; break; }
+    case 7: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = cs; break; }
     default: v = exp10_fast(a[i]); break;
   }
   out[i] = v;

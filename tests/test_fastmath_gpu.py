@@ -81,3 +81,23 @@ def test_newton_division(eng):
     ulps = np.abs(got - ref) / np.spacing(np.abs(ref))
     print("div: max %.2f ulp, inexact fraction %.2e" % (ulps.max(), np.mean(ulps > 0)))
     assert ulps.max() <= 1.0
+
+
+def test_box_muller_kernels(eng):
+    """ln on (0,1) and sin/cos(2 pi u): the short kernels behind the proposal normals and the
+    offset-lognormal deltas of the Cl path."""
+    rng = np.random.default_rng(4)
+    u = np.concatenate([rng.uniform(0, 1, 4000), 10 ** rng.uniform(-17, 0, 1000),
+                        10 ** rng.uniform(0, 6, 1000), [2.0 ** -54, 0.5, 0.7071067811865476, 1.0]])
+    u = u[u > 0]
+    w = ulp_err(eng.math_probe(5, u), [mp.log(mp.mpf(float(v))) for v in u])
+    print("log: max %.2f ulp" % w)
+    assert w <= 2.5
+    v = np.concatenate([rng.uniform(0, 1, 4000), [0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875]])
+    sn = eng.math_probe(6, v)
+    cs = eng.math_probe(7, v)
+    es = [mp.sin(2 * mp.pi * mp.mpf(float(t))) for t in v]
+    ec = [mp.cos(2 * mp.pi * mp.mpf(float(t))) for t in v]
+    # absolute accuracy is what the normals need (the exact values cross zero)
+    assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(sn, es)) <= 3e-16
+    assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(cs, ec)) <= 3e-16
