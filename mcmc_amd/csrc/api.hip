@@ -66,12 +66,12 @@ struct LaunchLnlike {
     const int bs = pick_block(C, c->nbm, ceil_div(n_eval, C), &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, C);
     const unsigned grid = static_cast<unsigned>(ceil_div(n_eval, bs));
-    MI355_HIP(hipEventRecord(c->ev0, c->stream));
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
     hipLaunchKernelGGL(k_sed_lnlike<M>, dim3(grid), dim3(bs), lds, c->stream, c->bands.p,
                        c->nb.p, c->nbm, s0, n_eval, C, theta, lnl, derived, c->kc);
     MI355_HIP(hipGetLastError());
-    MI355_HIP(hipEventRecord(c->ev1, c->stream));
-    c->ev_valid = true;
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    if (!c->capturing) c->ev_valid = true;
     return 0;
   }
 };
@@ -119,14 +119,14 @@ struct LaunchRun {
     const int bs = pick_block(c->C, c->nbm, c->S, &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
-    MI355_HIP(hipEventRecord(c->ev0, c->stream));
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
     if (c->kc.fast_ok != 0.0)
       hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
     else
       hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
     MI355_HIP(hipGetLastError());
-    MI355_HIP(hipEventRecord(c->ev1, c->stream));
-    c->ev_valid = true;
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    if (!c->capturing) c->ev_valid = true;
     return 0;
   }
 };

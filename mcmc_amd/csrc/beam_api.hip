@@ -119,7 +119,7 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
   a.chunk = static_cast<int>(chunk);
   a.nchunk = static_cast<int>(nchunk);
   a.partial = p->partial.p;
-  MI355_HIP(hipEventRecord(c->ev0, c->stream));
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
   // blockIdx.y is limited to 65535: slabs of maps
   for (int64_t s0 = 0; s0 < nm; s0 += 32768) {
     const int64_t ns = std::min<int64_t>(32768, nm - s0);
@@ -131,8 +131,8 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
                        dim3(256), 0, c->stream, b);
     MI355_HIP(hipGetLastError());
   }
-  MI355_HIP(hipEventRecord(c->ev1, c->stream));
-  c->ev_valid = true;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+  if (!c->capturing) c->ev_valid = true;
   hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
                      c->stream, n, static_cast<int>(nchunk), p->partial.p, lnL_dev);
   MI355_HIP(hipGetLastError());

@@ -162,7 +162,7 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   MI355_REQUIRE(a.rows < (int64_t{1} << 31), "too many rows (%lld) for one Cl launch",
                 static_cast<long long>(a.rows));
   auto fits = [&](int TR) { return form_lds_bytes(a.nbp, TR) <= kClLdsBudget; };
-  MI355_HIP(hipEventRecord(c->ev0, c->stream));
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
   // the widest row tile that fits in LDS and still leaves >= 2 blocks per CU's worth of work
   if (fits(64) && a.rows >= 64 * 512 && a.mode != CL_ROWS_TRIPLE) rc = launch_form_rt<4>(c, a);
@@ -173,8 +173,8 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
     return -1;
   }
   if (rc) return rc;
-  MI355_HIP(hipEventRecord(c->ev1, c->stream));
-  c->ev_valid = true;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+  if (!c->capturing) c->ev_valid = true;
   return 0;
 }
 

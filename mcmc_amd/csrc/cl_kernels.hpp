@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int n
   double s = 0.0;
   if (i < nb) {
     s = bp0[i];
+#pragma unroll 8
     for (int b = 0; b < npar; ++b) s = fma(q[static_cast<int64_t>(b) * n + c], K[b * nbp + i], s);
   }
   bp[static_cast<int64_t>(i) * n + c] = s;

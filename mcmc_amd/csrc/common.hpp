@@ -89,6 +89,7 @@ struct mi355_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the main kernel of the last call
   bool ev_valid = false;
+  bool capturing = false;         // the stream is being captured into a hipGraph: no events, no allocations
   uint64_t seed = 0;
 
   // --- SED catalogue -----------------------------------------------------------------

@@ -20,7 +20,21 @@ struct GmhState {
   DevBuf<int32_t> block_of, rank_in_block;
   std::vector<int32_t> h_block_of;
   int maxblk = 1;
+  // hipGraph replay of free-running steps (no trace, no injection)
+  DevBuf<GmhDyn> dyn;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_steps = 0;              // MH steps per graph launch
+  uint64_t graph_version = 0;       // version the graph was captured for
+  uint64_t version = 1;             // bumped whenever launch arguments may change
+  ~GmhState() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+  }
 };
+
+constexpr int kGraphSteps = 8;      // MH steps captured per graph
+constexpr int64_t kGraphMinSteps = 32;
 
 void gmh_destroy(GmhState* g) { delete g; }
 bool gmh_active(const mi355_ctx* c) { return c && c->gmh && c->gmh->active; }
@@ -116,6 +130,60 @@ static int finish_start(mi355_ctx* c, GmhArgs& a, const char* who) {
   return check_flags(c, who);
 }
 
+// launch the kernels of one MH step on the context stream
+static int launch_step(mi355_ctx* c, const GmhArgs& a) {
+  GmhState* g = c->gmh;
+  hipLaunchKernelGGL(k_gmh_propose, dim3(grid_for(c->N)), dim3(256), 0, c->stream, a);
+  MI355_HIP(hipGetLastError());
+  int rc = problem_lnlike(c, g->theta_new.p, g->lnl_new.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gmh_accept, dim3(grid_for(c->N)), dim3(256), 0, c->stream, a);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+// (Re)capture kGraphSteps MH steps whose counters come from g->dyn.  The caller has run at least
+// one step directly since the last (re)initialisation, so every scratch buffer has its final size.
+static int build_graph(mi355_ctx* c) {
+  GmhState* g = c->gmh;
+  if (g->graph_exec && g->graph_version == g->version) return 0;
+  if (g->graph_exec) { (void)hipGraphExecDestroy(g->graph_exec); g->graph_exec = nullptr; }
+  if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
+  if (g->dyn.alloc(1)) return -2;
+  GmhArgs a = base_args(c);
+  a.dyn = g->dyn.p;
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  c->capturing = true;
+  hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+  int rc = 0;
+  if (e == hipSuccess) {
+    for (int t = 0; t < kGraphSteps && rc == 0; ++t) {
+      rc = launch_step(c, a);
+      if (rc == 0) hipLaunchKernelGGL(k_gmh_advance, dim3(1), dim3(1), 0, c->stream, g->dyn.p, c->nblock);
+    }
+    hipGraph_t graph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+    if (rc == 0 && e2 == hipSuccess) {
+      g->graph = graph;
+      e = hipGraphInstantiate(&g->graph_exec, g->graph, nullptr, nullptr, 0);
+    } else {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e2 != hipSuccess) e = e2;
+    }
+  }
+  c->capturing = false;
+  if (rc) return rc;
+  if (e != hipSuccess || !g->graph_exec) {
+    (void)hipGetLastError();
+    g->graph_exec = nullptr;
+    set_error("hipGraph capture of the MH step failed: %s", hipGetErrorString(e));
+    return -2;
+  }
+  g->graph_steps = kGraphSteps;
+  g->graph_version = g->version;
+  return 0;
+}
+
 int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, const double* inj_u) {
   GmhState* g = c->gmh;
   MI355_REQUIRE(nsteps >= 0 && thin >= 0, "negative nsteps/thin");
@@ -137,7 +205,29 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     if (c->tr_theta.alloc(rows * P) || c->tr_lnPr.alloc(rows) || c->tr_acc.alloc(rows)) return -2;
   }
   int64_t row = 0;
-  for (int64_t t = 0; t < nsteps; ++t) {
+  int64_t t0 = 0;
+  if (!inj_n && c->nkeep == 0 && nsteps >= kGraphMinSteps) {
+    // free-running production steps: one step directly (sizes every scratch buffer), then
+    // replays of a captured graph of kGraphSteps steps, the remainder directly
+    GmhArgs a = base_args(c);
+    a.blk = c->nblock ? static_cast<int>(c->stage_step % c->nblock) : 0;
+    a.step = c->step_total;
+    a.nsamp = c->nsamp;
+    int rc = launch_step(c, a);
+    if (rc) return rc;
+    t0 = 1;
+    rc = build_graph(c);
+    if (rc) return rc;
+    GmhDyn d{c->step_total + 1, c->nsamp + 1,
+             c->nblock ? static_cast<int32_t>((c->stage_step + 1) % c->nblock) : 0, 0};
+    MI355_HIP(hipMemcpyAsync(g->dyn.p, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));   // d lives on this stack frame
+    while (nsteps - t0 >= g->graph_steps) {
+      MI355_HIP(hipGraphLaunch(g->graph_exec, c->stream));
+      t0 += g->graph_steps;
+    }
+  }
+  for (int64_t t = t0; t < nsteps; ++t) {
     GmhArgs a = base_args(c);
     a.blk = c->nblock ? static_cast<int>((c->stage_step + t) % c->nblock) : 0;
     a.step = c->step_total + t;
@@ -152,12 +242,8 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
       a.tr_acc = c->tr_acc.p + static_cast<size_t>(row) * N;
       ++row;
     }
-    hipLaunchKernelGGL(k_gmh_propose, dim3(grid_for(N)), dim3(256), 0, c->stream, a);
-    MI355_HIP(hipGetLastError());
-    int rc = problem_lnlike(c, g->theta_new.p, g->lnl_new.p);
+    int rc = launch_step(c, a);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gmh_accept, dim3(grid_for(N)), dim3(256), 0, c->stream, a);
-    MI355_HIP(hipGetLastError());
   }
   c->step_total += nsteps;
   c->stage_step += nsteps;
@@ -194,6 +280,7 @@ int gmh_adapt(mi355_ctx* c, double fac, int random_restart, int no_correlations,
   hipLaunchKernelGGL(k_gmh_adapt, dim3(grid_for(c->N)), dim3(256), 0, c->stream, a);
   MI355_HIP(hipGetLastError());
   g->mode = corr ? (rotate ? GMH_ROTATE : GMH_CORR) : GMH_UNCORR;
+  g->version += 1;
   set_npn(c);
   a = base_args(c);
   a.randomize = 1;
@@ -303,6 +390,7 @@ int mi355_mh_init_problem(mi355_ctx* c, int32_t problem, int32_t C, const double
   if (upload(sigma, sigma_per_chain, c->scratch_c, c->scratch_b)) return -2;
   MI355_HIP(hipMemsetAsync(c->flags.p, 0, c->N * sizeof(int32_t), c->stream));
   g->active = true;
+  g->version += 1;
   GmhArgs a = base_args(c);
   a.center = c->scratch_a.p;
   a.center_per_chain = theta0_per_chain;
@@ -327,6 +415,7 @@ int mi355_mh_set_sqrt_matrix(mi355_ctx* c, const double* L, int32_t per_chain, i
   if (!L) {
     MI355_REQUIRE(!rotate, "rotateParams needs a sqrt matrix");
     g->mode = GMH_UNCORR;
+    g->version += 1;
     set_npn(c);
     return 0;
   }
@@ -339,6 +428,7 @@ int mi355_mh_set_sqrt_matrix(mi355_ctx* c, const double* L, int32_t per_chain, i
   MI355_HIP(hipGetLastError());
   MI355_HIP(hipStreamSynchronize(c->stream));
   g->mode = rotate ? GMH_ROTATE : GMH_CORR;
+  g->version += 1;
   set_npn(c);
   return 0;
 }

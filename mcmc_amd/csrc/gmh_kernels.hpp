@@ -48,6 +48,7 @@ __device__ __forceinline__ double gmh_sed_pp(const GmhProblem& pb, double* col, 
 __device__ __forceinline__ double gmh_package_prior(const GmhProblem& pb, double* col, int64_t N) {
   if (pb.kind == GMH_CL) {                                 // binnedClModel.py:125-132, package = asarray
     double p = 1.0;
+#pragma unroll 8
     for (int b = 0; b < pb.P; ++b)
       if (pb.cltype[b] != 1 && col[b * N] < 0) p = 0.0;
     return p;
@@ -73,6 +74,15 @@ __device__ __forceinline__ double gmh_package_prior(const GmhProblem& pb, double
     default: return gmh_sed_pp<MI355_SED_THICK_LOGA>(pb, col, N);
   }
 }
+
+// Per-step counters kept on the device so that a captured hipGraph of MH steps can be replayed:
+// the kernels of a graph have frozen arguments, what changes from step to step lives here.
+struct GmhDyn {
+  int64_t step;    // global step (Philox position)
+  int64_t nsamp;   // samples in the moments before this step
+  int32_t blk;     // block of this step
+  int32_t pad;
+};
 
 struct GmhArgs {
   GmhProblem pb;
@@ -101,6 +111,7 @@ struct GmhArgs {
   int64_t step;             // global step (Philox position)
   int64_t nsamp;            // samples in the moments before this step
   int64_t stage;
+  const GmhDyn* dyn;        // non-null: step / nsamp / blk come from here (graph replay)
   // injection (parity mode)
   const double* inj_n;      // [P] normals of this step for chain n at inj_n[n*P + .]
   const double* inj_u;      // [N]
@@ -131,8 +142,13 @@ __global__ __launch_bounds__(256) void k_gmh_propose(GmhArgs a) {
   const int P = a.pb.P;
   const int64_t N = a.N;
   const bool inject = a.inj_n != nullptr;
+  if (a.dyn) {
+    a.step = a.dyn->step;
+    a.blk = a.dyn->blk;
+  }
   const uint64_t base = static_cast<uint64_t>(a.step) * a.npn;
   if (a.mode == GMH_UNCORR) {
+#pragma unroll 8
     for (int i = 0; i < P; ++i) {
       double v = a.theta[i * N + n];
       if (gmh_in_block(a, i)) {                            // :151, :156-159
@@ -175,6 +191,11 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   if (n >= a.N) return;
   const int P = a.pb.P;
   const int64_t N = a.N;
+  if (a.dyn) {
+    a.step = a.dyn->step;
+    a.nsamp = a.dyn->nsamp;
+    a.blk = a.dyn->blk;
+  }
   const double prior = a.prior_new[n];
   double v = a.lnl_new[n];
   const double prev = a.lnPr[n];
@@ -200,6 +221,7 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   const double cnt = static_cast<double>(a.nsamp + 1);
   const double rn = rcp_nr(cnt);                           // as the fused kernel
   const double cf = 1.0 - rn;
+#pragma unroll 4
   for (int i = 0; i < P; ++i) {
     double x = a.theta[i * N + n];
     if (accepted) {
@@ -224,6 +246,13 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
     a.tr_lnPr[n] = lp;
     a.tr_acc[n] = accepted ? 1 : 0;
   }
+}
+
+// one thread: next step's counters (graph replay)
+__global__ void k_gmh_advance(GmhDyn* dyn, int nblock) {
+  dyn->step += 1;
+  dyn->nsamp += 1;
+  if (nblock) dyn->blk = (dyn->blk + 1 == nblock) ? 0 : dyn->blk + 1;
 }
 
 // newMCMC (MCMC.py:343-413): centre = package(mean), stdevs = package(stdev), sigma =

@@ -232,3 +232,42 @@ def test_stepwise_errors():
         with pytest.raises(Mi355Error, match="no binned Cl problem"):
             eng.cl_npar = 3
             eng.mh_init_problem("cl", 2, np.ones(3), np.ones(3))
+
+
+@pytest.mark.parametrize("kind", ["cl", "beam", "sed"])
+def test_graph_replay_equals_direct_launches(kind):
+    """Long free-running runs replay a captured hipGraph of 8 MH steps; a run that keeps a trace
+    launches every step directly.  Same seed -> same chains, bit for bit."""
+    from oracle import refbeam as RB
+    from oracle import refcl as RC
+    from mcmc_amd import Engine, synth
+    res = []
+    for traced in (False, True):
+        with Engine(seed=2024) as eng:
+            if kind == "cl":
+                model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.0, lmax=700, seed=5)
+                eng.cl_load([d])
+                eng.cl_set_binning(model.bins, model.shapefun)
+                eng.mh_init_problem("cl", 40, truth, np.full(6, 0.03), param_blocks=np.arange(6),
+                                    track_cov=True)
+            elif kind == "beam":
+                x, y, dm, noise, tr, prior = RB.synth_beam_maps(3, n=32, seed=2)
+                eng.beam_load(x, y, dm, noise, center_min=prior.center_min, center_max=prior.center_max,
+                              sig_min=prior.sig_min, sig_max=prior.sig_max)
+                sg = np.array([0.05, 0.05, 0.05, 0.05, 0.02, 0.1, 0.002, 0, 0])
+                eng.mh_init_problem("beam", 8, tr[:, None, :].repeat(8, 1), sg, param_blocks=np.arange(7))
+            else:
+                nu, d, sig, _ = synth.sed_catalogue(4, seed=3)
+                eng.sed_load("M2N", np.full(4, 8, np.int32), nu, d, sig)
+                eng.mh_init_problem("sed", 32, synth.M2N_START, synth.M2N_PROP_SIGMAS,
+                                    param_blocks=np.arange(6))
+            eng.mh_run(77, thin=1 if traced else 0)
+            if kind == "cl":
+                eng.mh_adapt_corr(rotate=True)
+            else:
+                eng.mh_adapt()
+            eng.mh_run(53, thin=1 if traced else 0)
+            eng.mh_run(40, thin=1 if traced else 0)      # second replay of the same graph
+            res.append(eng.mh_moments())
+    for key in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
+        assert np.array_equal(res[0][key], res[1][key]), key
