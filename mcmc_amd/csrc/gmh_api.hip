@@ -33,7 +33,7 @@ struct GmhState {
   }
 };
 
-constexpr int kGraphSteps = 8;      // MH steps captured per graph
+constexpr int kGraphSteps = 8;      // MH steps captured per graph (even: two counter slots)
 constexpr int64_t kGraphMinSteps = 32;
 
 void gmh_destroy(GmhState* g) { delete g; }
@@ -82,6 +82,8 @@ static GmhArgs base_args(mi355_ctx* c) {
   a.npn = c->npn;
   a.seed = c->seed;
   a.stage = c->stage;
+  // few chains: more groups per chain (shorter per-thread loops); many: wider coalesced segments
+  a.cb_shift = c->N <= 2048 ? 3 : (g->pb.P < 128 ? 5 : 4);
   return a;
 }
 
@@ -133,11 +135,14 @@ static int finish_start(mi355_ctx* c, GmhArgs& a, const char* who) {
 // launch the kernels of one MH step on the context stream
 static int launch_step(mi355_ctx* c, const GmhArgs& a) {
   GmhState* g = c->gmh;
-  hipLaunchKernelGGL(k_gmh_propose, dim3(grid_for(c->N)), dim3(256), 0, c->stream, a);
+  const int cb = 1 << a.cb_shift;
+  const unsigned grid = static_cast<unsigned>(ceil_div64(c->N, cb));
+  const size_t lds = static_cast<size_t>(a.pb.P + 1) * cb * sizeof(double);
+  hipLaunchKernelGGL(k_gmh_propose, dim3(grid), dim3(256), lds, c->stream, a);
   MI355_HIP(hipGetLastError());
   int rc = problem_lnlike(c, g->theta_new.p, g->lnl_new.p);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gmh_accept, dim3(grid_for(c->N)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_gmh_accept, dim3(grid), dim3(256), lds, c->stream, a);
   MI355_HIP(hipGetLastError());
   return 0;
 }
@@ -149,17 +154,17 @@ static int build_graph(mi355_ctx* c) {
   if (g->graph_exec && g->graph_version == g->version) return 0;
   if (g->graph_exec) { (void)hipGraphExecDestroy(g->graph_exec); g->graph_exec = nullptr; }
   if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
-  if (g->dyn.alloc(1)) return -2;
+  if (g->dyn.alloc(2)) return -2;
   GmhArgs a = base_args(c);
-  a.dyn = g->dyn.p;
   MI355_HIP(hipStreamSynchronize(c->stream));
   c->capturing = true;
   hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
   int rc = 0;
   if (e == hipSuccess) {
-    for (int t = 0; t < kGraphSteps && rc == 0; ++t) {
+    for (int t = 0; t < kGraphSteps && rc == 0; ++t) {   // counters ping-pong between two slots
+      a.dyn = g->dyn.p + (t & 1);
+      a.dyn_next = g->dyn.p + ((t & 1) ^ 1);
       rc = launch_step(c, a);
-      if (rc == 0) hipLaunchKernelGGL(k_gmh_advance, dim3(1), dim3(1), 0, c->stream, g->dyn.p, c->nblock);
     }
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);

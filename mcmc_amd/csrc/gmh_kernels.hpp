@@ -112,6 +112,8 @@ struct GmhArgs {
   int64_t nsamp;            // samples in the moments before this step
   int64_t stage;
   const GmhDyn* dyn;        // non-null: step / nsamp / blk come from here (graph replay)
+  GmhDyn* dyn_next;         // non-null: k_gmh_accept writes the next step's counters here
+  int cb_shift;             // log2(chains per block) of the step kernels
   // injection (parity mode)
   const double* inj_n;      // [P] normals of this step for chain n at inj_n[n*P + .]
   const double* inj_u;      // [N]
@@ -135,124 +137,233 @@ __device__ __forceinline__ bool gmh_in_block(const GmhArgs& a, int i) {
   return a.nblock == 0 || a.block_of[i] == a.blk;
 }
 
+// Thread layout of the two step kernels: a block of 256 threads serves cb = 2^cb_shift chains,
+// thread = (chain-in-block, group), the G = 256/cb groups share the per-parameter work of a
+// chain.  Loads are coalesced over the chains (cb*8 bytes per segment) and a step costs a few
+// memory round trips per thread instead of P (or P^2/2 for the co-moments) in sequence.
+struct GmhLane {
+  int cb, G, cl, grp;
+  int64_t n;
+  bool valid;
+};
+__device__ __forceinline__ GmhLane gmh_lane(const GmhArgs& a) {
+  GmhLane t;
+  t.cb = 1 << a.cb_shift;
+  t.G = 256 >> a.cb_shift;
+  t.cl = threadIdx.x & (t.cb - 1);
+  t.grp = threadIdx.x >> a.cb_shift;
+  t.n = static_cast<int64_t>(blockIdx.x) * t.cb + t.cl;
+  t.valid = t.n < a.N;
+  return t;
+}
+
+// normals of parameters (i0, i0+1) with stream indices x0, x1; one Philox block + Box-Muller
+// when the two are the halves of one pair (same values as two philox_normal calls)
+__device__ __forceinline__ void gmh_normal_pair(const GmhArgs& a, int64_t n, bool in0, bool in1,
+                                                uint64_t x0, uint64_t x1, double& z0, double& z1) {
+  z0 = 0.0;
+  z1 = 0.0;
+  if (in0 && in1 && !(x0 & 1) && x1 == x0 + 1) {
+    philox_normal2(a.seed, RNG_NORMAL, n, x0 >> 1, z0, z1);
+  } else {
+    if (in0) z0 = philox_normal(a.seed, RNG_NORMAL, n, x0);
+    if (in1) z1 = philox_normal(a.seed, RNG_NORMAL, n, x1);
+  }
+}
+
 // getNewParams (Proposal.py:127-164) + package + prior for every chain
+// dynamic LDS: z[P][cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_propose(GmhArgs a) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (n >= a.N) return;
+  extern __shared__ double gmh_lds[];
+  const GmhLane t = gmh_lane(a);
   const int P = a.pb.P;
-  const int64_t N = a.N;
+  const int64_t N = a.N, n = t.n;
   const bool inject = a.inj_n != nullptr;
   if (a.dyn) {
     a.step = a.dyn->step;
     a.blk = a.dyn->blk;
   }
   const uint64_t base = static_cast<uint64_t>(a.step) * a.npn;
+  double* z = gmh_lds;
   if (a.mode == GMH_UNCORR) {
-#pragma unroll 8
-    for (int i = 0; i < P; ++i) {
-      double v = a.theta[i * N + n];
-      if (gmh_in_block(a, i)) {                            // :151, :156-159
-        const double z = inject ? a.inj_n[n * P + i]
-                                : philox_normal(a.seed, RNG_NORMAL, n, base + a.rank_in_block[i]);
-        v += z * a.sigma[i * N + n];
+    if (t.valid) {
+      for (int i0 = 2 * t.grp; i0 < P; i0 += 2 * t.G) {
+        const int i1 = i0 + 1;
+        const bool in0 = gmh_in_block(a, i0), in1 = i1 < P && gmh_in_block(a, i1);   // :151
+        double z0, z1;
+        if (inject) {
+          z0 = in0 ? a.inj_n[n * P + i0] : 0.0;
+          z1 = in1 ? a.inj_n[n * P + i1] : 0.0;
+        } else {
+          gmh_normal_pair(a, n, in0, in1, base + (in0 ? a.rank_in_block[i0] : 0),
+                          base + (in1 ? a.rank_in_block[i1] : 0), z0, z1);
+        }
+        double v = a.theta[i0 * N + n];
+        if (in0) v += z0 * a.sigma[i0 * N + n];            // :156-159
+        a.theta_new[i0 * N + n] = v;
+        if (i1 < P) {
+          v = a.theta[i1 * N + n];
+          if (in1) v += z1 * a.sigma[i1 * N + n];
+          a.theta_new[i1 * N + n] = v;
+        }
       }
-      a.theta_new[i * N + n] = v;
     }
-  } else if (a.mode == GMH_CORR) {
-    for (int j = 0; j < P; ++j)
-      a.zbuf[j * N + n] = inject ? a.inj_n[n * P + j] : philox_normal(a.seed, RNG_NORMAL, n, base + j);
-    for (int i = 0; i < P; ++i) {
-      double v = a.theta[i * N + n];
-      if (gmh_in_block(a, i)) {                            // :153-159
-        double s = 0.0;
-        for (int j = 0; j < P; ++j) s += a.L[(static_cast<int64_t>(i) * P + j) * N + n] * a.zbuf[j * N + n];
-        v += s * a.sigma[i * N + n];
+  } else {
+    // the normals of the step into LDS, then one matrix row per (chain, group) turn
+    if (t.valid) {
+      if (a.mode == GMH_CORR) {                            // z_j = normal(base + j), all j
+        if (inject) {
+          for (int j = t.grp; j < P; j += t.G) z[j * t.cb + t.cl] = a.inj_n[n * P + j];
+        } else {
+          const int odd = static_cast<int>(base & 1);
+          for (int q = t.grp; 2 * q - odd < P; q += t.G) {
+            const int j0 = 2 * q - odd, j1 = j0 + 1;
+            double za, zb;
+            philox_normal2(a.seed, RNG_NORMAL, n, (base >> 1) + q, za, zb);
+            if (j0 >= 0) z[j0 * t.cb + t.cl] = za;
+            if (j1 < P) z[j1 * t.cb + t.cl] = zb;
+          }
+        }
+      } else {                                             // rotated: the block's normals by rank
+        for (int j = t.grp; j < P; j += t.G)
+          if (gmh_in_block(a, j))
+            z[j * t.cb + t.cl] = inject ? a.inj_n[n * P + a.rank_in_block[j]]
+                                        : philox_normal(a.seed, RNG_NORMAL, n, base + a.rank_in_block[j]);
       }
-      a.theta_new[i * N + n] = v;
     }
-  } else {                                                 // rotated, :145-148
-    for (int j = 0; j < P; ++j)
-      if (gmh_in_block(a, j))
-        a.zbuf[j * N + n] = inject ? a.inj_n[n * P + a.rank_in_block[j]]
-                                   : philox_normal(a.seed, RNG_NORMAL, n, base + a.rank_in_block[j]);
-    for (int i = 0; i < P; ++i) {
-      double s = 0.0;                                      // sum() starts from 0
-      for (int j = 0; j < P; ++j)
-        if (gmh_in_block(a, j)) s += a.L[(static_cast<int64_t>(i) * P + j) * N + n] * a.zbuf[j * N + n];
-      a.theta_new[i * N + n] = a.theta[i * N + n] + s * a.sigma[i * N + n];
+    __syncthreads();
+    if (t.valid) {
+      for (int i = t.grp; i < P; i += t.G) {
+        double v = a.theta[i * N + n];
+        const double* Li = a.L + static_cast<int64_t>(i) * P * N + n;
+        if (a.mode == GMH_CORR) {
+          if (gmh_in_block(a, i)) {                        // :153-159
+            double s = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < P; ++j) s += Li[j * N] * z[j * t.cb + t.cl];
+            v += s * a.sigma[i * N + n];
+          }
+        } else {                                           // :145-148, sum() starts from 0
+          double s = 0.0;
+          for (int j = 0; j < P; ++j)
+            if (gmh_in_block(a, j)) s += Li[j * N] * z[j * t.cb + t.cl];
+          v += s * a.sigma[i * N + n];
+        }
+        a.theta_new[i * N + n] = v;
+      }
     }
   }
-  a.prior_new[n] = gmh_package_prior(a.pb, a.theta_new + n, N);   // :164, MCMC.py:245
+  __syncthreads();                                         // theta_new of the block's chains is complete
+  if (t.valid && t.grp == 0)
+    a.prior_new[n] = gmh_package_prior(a.pb, a.theta_new + n, N);   // :164, MCMC.py:245
+}
+
+// (i, j), j <= i, of entry e of the row-major lower triangle
+__device__ __forceinline__ void gmh_tri_decode(int e, int& i, int& j) {
+  i = static_cast<int>((sqrtf(8.0f * static_cast<float>(e) + 1.0f) - 1.0f) * 0.5f);
+  while (i * (i + 1) / 2 > e) --i;
+  while ((i + 1) * (i + 2) / 2 <= e) ++i;
+  j = e - i * (i + 1) / 2;
 }
 
 // accept / reject (MCMC.py:236-279), running moments (:290-340), trace
+// dynamic LDS: d[P][cb] doubles + accepted[cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
-  const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (n >= a.N) return;
+  extern __shared__ double gmh_lds[];
+  const GmhLane t = gmh_lane(a);
   const int P = a.pb.P;
-  const int64_t N = a.N;
+  const int64_t N = a.N, n = t.n;
   if (a.dyn) {
     a.step = a.dyn->step;
     a.nsamp = a.dyn->nsamp;
     a.blk = a.dyn->blk;
   }
-  const double prior = a.prior_new[n];
-  double v = a.lnl_new[n];
-  const double prev = a.lnPr[n];
-  bool accepted = false;
-  const bool bad = (v != v) || (v == -__builtin_inf());    // :238-243
-  if (prior > 0.0 && !bad) {
-    if (prior != 1.0) v += log(prior);                     // :250
-    const double lnalpha = v - prev;                       // :251-252
-    bool reject = false;
-    if (!(lnalpha >= 0.0)) {
-      const double u = a.inj_u ? a.inj_u[n]
-                               : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
-      reject = !(exp_fast(lnalpha) > u);                   // :264
+  double* d = gmh_lds;
+  double* dec = gmh_lds + P * t.cb;
+  if (t.valid && t.grp == 0) {
+    const double prior = a.prior_new[n];
+    double v = a.lnl_new[n];
+    const double prev = a.lnPr[n];
+    bool accepted = false;
+    const bool bad = (v != v) || (v == -__builtin_inf());  // :238-243
+    if (prior > 0.0 && !bad) {
+      if (prior != 1.0) v += log(prior);                   // :250
+      const double lnalpha = v - prev;                     // :251-252
+      bool reject = false;
+      if (!(lnalpha >= 0.0)) {
+        const double u = a.inj_u ? a.inj_u[n]
+                                 : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
+        reject = !(exp_fast(lnalpha) > u);                 // :264
+      }
+      accepted = !reject;
     }
-    accepted = !reject;
+    if (accepted) {
+      a.lnPr[n] = v;
+      a.naccept[n] += 1;                                   // :269
+      if (a.nblock) a.accept[static_cast<int64_t>(a.blk) * N + n] += 1;   // :271
+    }
+    if (a.tr_theta) {
+      a.tr_lnPr[n] = accepted ? v : prev;
+      a.tr_acc[n] = accepted ? 1 : 0;
+    }
+    dec[t.cl] = accepted ? 1.0 : 0.0;
+    if (n == 0 && a.dyn_next) {                            // next step's counters (graph replay):
+      GmhDyn nx;                                           // the other slot, nobody reads it now
+      nx.step = a.step + 1;
+      nx.nsamp = a.nsamp + 1;
+      nx.blk = a.nblock ? ((a.blk + 1 == a.nblock) ? 0 : a.blk + 1) : 0;
+      nx.pad = 0;
+      *a.dyn_next = nx;
+    }
   }
-  if (accepted) {
-    a.lnPr[n] = v;
-    a.naccept[n] += 1;                                     // :269
-    if (a.nblock) a.accept[static_cast<int64_t>(a.blk) * N + n] += 1;   // :271
-  }
-  const double lp = accepted ? v : prev;
+  __syncthreads();
   const double cnt = static_cast<double>(a.nsamp + 1);
   const double rn = rcp_nr(cnt);                           // as the fused kernel
   const double cf = 1.0 - rn;
+  if (t.valid) {
+    const bool accepted = dec[t.cl] != 0.0;
 #pragma unroll 4
-  for (int i = 0; i < P; ++i) {
-    double x = a.theta[i * N + n];
-    if (accepted) {
-      x = a.theta_new[i * N + n];
-      a.theta[i * N + n] = x;
+    for (int i = t.grp; i < P; i += t.G) {
+      double x = a.theta[i * N + n];
+      if (accepted) {
+        x = a.theta_new[i * N + n];
+        a.theta[i * N + n] = x;
+      }
+      const double mu = a.mean[i * N + n];
+      const double dlt = x - mu;
+      d[i * t.cb + t.cl] = dlt;
+      const double mu1 = mu + dlt * rn;
+      a.mean[i * N + n] = mu1;
+      a.m2[i * N + n] += dlt * (x - mu1);
+      if (a.tr_theta) a.tr_theta[i * N + n] = x;
     }
-    const double mu = a.mean[i * N + n];
-    const double dlt = x - mu;
-    if (a.comom) {
-      // C_ij += (n-1)/n d_i d_j with d = x - mean_old, j <= i (symmetric by construction);
-      // d_j of the earlier parameters is kept in zbuf
-      a.zbuf[i * N + n] = dlt;
-      for (int j = 0; j <= i; ++j)
-        a.comom[(static_cast<int64_t>(i) * P + j) * N + n] += cf * dlt * a.zbuf[j * N + n];
+  }
+  if (a.comom == nullptr) return;                          // uniform over the grid
+  __syncthreads();
+  if (!t.valid) return;
+  // C_ij += (n-1)/n d_i d_j with d = x - mean_old, j <= i (symmetric by construction); the
+  // triangle's entries are dealt round-robin to the groups, eight loads in flight per thread
+  const int T = P * (P + 1) / 2;
+  constexpr int U = 8;
+  for (int e0 = t.grp; e0 < T; e0 += t.G * U) {
+    double* ptr[U];
+    double inc[U], cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * t.G;
+      ptr[u] = nullptr;
+      if (e < T) {
+        int i, j;
+        gmh_tri_decode(e, i, j);
+        ptr[u] = a.comom + (static_cast<int64_t>(i) * P + j) * N + n;
+        inc[u] = cf * d[i * t.cb + t.cl] * d[j * t.cb + t.cl];
+        cur[u] = *ptr[u];
+      }
     }
-    const double mu1 = mu + dlt * rn;
-    a.mean[i * N + n] = mu1;
-    a.m2[i * N + n] += dlt * (x - mu1);
-    if (a.tr_theta) a.tr_theta[i * N + n] = x;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ptr[u]) *ptr[u] = cur[u] + inc[u];
   }
-  if (a.tr_theta) {
-    a.tr_lnPr[n] = lp;
-    a.tr_acc[n] = accepted ? 1 : 0;
-  }
-}
-
-// one thread: next step's counters (graph replay)
-__global__ void k_gmh_advance(GmhDyn* dyn, int nblock) {
-  dyn->step += 1;
-  dyn->nsamp += 1;
-  if (nblock) dyn->blk = (dyn->blk + 1 == nblock) ? 0 : dyn->blk + 1;
 }
 
 // newMCMC (MCMC.py:343-413): centre = package(mean), stdevs = package(stdev), sigma =
