@@ -59,11 +59,32 @@ def cpu_baseline(nu, d, sig, seconds=12.0):
             if np.any(np.isfinite(e)):
                 ess_sum += float(np.nanmin(e))
     ess_rate = ess_sum / t_used if t_used > 0 else None
-    return {"value": done / t_used, "unit": "evals/s", "cores": 1, "kind": "port",
-            "ess_per_sec": ess_rate,
-            "sample": "%d MH steps of oracle/refcpu.py (pure Python+NumPy restatement, one step "
-                      "at a time) on the first %d sources of the same catalogue, 1 chain each, "
-                      "%.1f s" % (done, nsrc, t_used)}
+    out = {"value": done / t_used, "unit": "evals/s", "cores": 1, "kind": "port",
+           "ess_per_sec": ess_rate,
+           "sample": "%d MH steps of oracle/refcpu.py (pure Python+NumPy restatement, one step "
+                     "at a time) on the first %d sources of the same catalogue, 1 chain each, "
+                     "%.1f s" % (done, nsrc, t_used)}
+    out.update(cpu_vectorised(seconds=4.0))
+    return out
+
+
+def cpu_vectorised(seconds=4.0):
+    """SURVEY 8(d)'s "best-effort CPU" lines: the same MH transition vectorised with NumPy over
+    64 sources x 64 chains per process (oracle/refcpu.VectorChainsM2N), on one core and on the
+    box's CPU share.  Must run before this process touches the GPU (it forks workers)."""
+    import multiprocessing as mp
+    from oracle import refcpu as R
+    from mcmc_amd import synth
+    sig, start = np.asarray(synth.M2N_PROP_SIGMAS, float), np.asarray(synth.M2N_START, float)
+    done, t = R.vector_m2n_rate((0, 64, 64, seconds, sig, start))
+    cores = max(1, min(16, os.cpu_count() or 1))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(R.vector_m2n_rate, [(64 * k, 64, 64, seconds, sig, start) for k in range(cores)])
+    return {"vectorised": {"value": done / t, "unit": "evals/s", "cores": 1, "kind": "port",
+                           "sample": "NumPy-vectorised MH over 64 sources x 64 chains, %.1f s" % t},
+            "vectorised_all_cores": {"value": sum(r[0] / r[1] for r in res), "unit": "evals/s",
+                                     "cores": cores, "kind": "port",
+                                     "sample": "the same in %d processes on distinct sources" % cores}}
 
 
 def main():
@@ -80,6 +101,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    # CPU baselines first: the multi-core line forks workers, which must happen before this
+    # process initialises the GPU.  N=1 only (rank 0 of a single-process run).
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        from mcmc_amd import synth as _synth
+        nu0, d0, sig0, _ = _synth.sed_catalogue(args.sources)
+        cpu = cpu_baseline(nu0, d0, sig0, args.cpu_seconds)
 
     import torch
     from mcmc_amd import Engine, synth
@@ -192,8 +221,8 @@ def main():
         "rhat_median": float(torch.nanmedian(rhat).item()),
     }
     out.update(ess_out)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(nu, d, sig, args.cpu_seconds)
+    if rank == 0 and cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     eng.close()
