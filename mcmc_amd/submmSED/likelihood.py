@@ -15,20 +15,7 @@ dodet = False     # likelihood.py:15
 _MARGINALISED = (MODEL_IDS["M1"], MODEL_IDS["M2"])
 
 
-def catalogue_arrays(datasets):
-    """Pack submmData objects into the [S, nb_max] arrays mi355_sed_load takes."""
-    nb = np.array([np.size(d.d) for d in datasets], dtype=np.int32)
-    nbm = max(int(nb.max()), 1)
-    S = len(datasets)
-    nu = np.full((S, nbm), _model.nu_b)
-    dd = np.zeros((S, nbm))
-    sg = np.ones((S, nbm))
-    for s, d in enumerate(datasets):
-        n = nb[s]
-        nu[s, :n] = np.ravel(d.freq)
-        dd[s, :n] = np.ravel(d.d)
-        sg[s, :n] = np.broadcast_to(np.ravel(d.sig), (n,))
-    return nb, nu, dd, sg
+from .data import catalogue_arrays  # noqa: E402,F401  (packs ragged data sets for mi355_sed_load)
 
 
 class _SEDLikelihood(Likelihood.Likelihood):

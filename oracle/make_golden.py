@@ -704,9 +704,121 @@ def golden_beam(R):
     print("wrote beam_g6.npz")
 
 
+# ---------------------------------------------------------------------------------------------
+# G7: catalogue readers (submmSED/data.py:75-607) on excerpts of the data files the reference
+# ships.  The excerpts (data, a few KB each) are written to tests/golden/catalogues/ and are the
+# inputs of tests/test_catalogue_readers.py; the .npz holds what the reference's readers return
+# for exactly those files.
+# ---------------------------------------------------------------------------------------------
+def _pack_datasets(prefix, dsets, out):
+    def clean(n):                                          # str(bytes) artefact of the 'a12' fields
+        n = str(n)
+        if n.startswith("b'") and n.endswith("'"):
+            n = n[2:-1]
+        return n
+    out[prefix + "/name"] = np.array([clean(d.name) for d in dsets])
+    out[prefix + "/z"] = np.array([float(d.z) for d in dsets])
+    out[prefix + "/nb"] = np.array([np.size(d.d) for d in dsets], dtype=np.int64)
+    for key, get in (("freq", lambda d: d.freq), ("d", lambda d: d.d), ("sig", lambda d: d.sig),
+                     ("freq_obs", lambda d: d.freq_obs)):
+        parts = [np.ravel(np.asarray(get(d), dtype=np.float64)) for d in dsets]
+        parts = [q if q.size == np.size(d.d) else np.full(np.size(d.d), np.nan)
+                 for q, d in zip(parts, dsets)]
+        out[prefix + "/" + key] = np.concatenate(parts) if parts else np.zeros(0)
+    if dsets and getattr(dsets[0], "z_alt", None) is not None:
+        out[prefix + "/z_alt"] = np.array([float(d.z_alt) for d in dsets])
+        out[prefix + "/name_alt"] = np.array([str(d.name_alt) for d in dsets])
+
+
+def golden_readers(R):
+    import contextlib
+    import io
+    D = R["submmSED.data"]
+    src = os.path.join(REF, "MCMC", "submmSED")
+    cat = os.path.join(OUT, "catalogues")
+    os.makedirs(cat, exist_ok=True)
+
+    def excerpt(rel, dst, keep):
+        with open(os.path.join(src, rel)) as f:
+            lines = f.readlines()
+        with open(os.path.join(cat, dst), "w") as f:
+            f.writelines(keep(lines))
+        return os.path.join(cat, dst)
+
+    out = {}
+
+    def run(prefix, fn):
+        with contextlib.redirect_stdout(io.StringIO()):
+            _pack_datasets(prefix, fn(), out)
+
+    mrr = excerpt("dat/ERCSCiifsczbg.dat", "mrr_new.dat", lambda L: L[:60])
+    run("mrr_default", lambda: D.readfluxes_MRR(mrr))
+    run("mrr_dlc1", lambda: D.readfluxes_MRR(mrr, IRAS_ignore=[0], Planck_ignore=[3], DLC_ul=True, next0=True))
+    run("mrr_dlc2", lambda: D.readfluxes_MRR(mrr, IRAS_ignore=[0], Planck_ignore=[2, 3], DLC_ul=True, next0=False))
+    run("mrr_nocx", lambda: D.readfluxes_MRR(mrr, colorx=[1.0, 1.0, 1.0, 1.0], next0=False))
+    mrro = excerpt("dat/ERCSCalliifscz4550850.dat", "mrr_old.dat", lambda L: L[:25])
+    run("mrr_old", lambda: D.readfluxes_MRR(mrro, old_MRR=True, next0=False))
+
+    dlc0 = excerpt("dat/submmSED.txt", "dlc_format0.txt", lambda L: L)
+    run("dlc0", lambda: D.readfluxes_DLC(dlc0, format=0))
+
+    # DLC_2014: under NumPy >= 2.2 the reference's `if l25:` raises on sources without a 25 um
+    # point, so UL25=True is pinned on the rows that have one and the parsing on all rows with
+    # UL25=False.  getArp220 needs pkg_resources on the real package; its branch is pinned by G2.
+    herus = excerpt("dat/herus_phot.csv", "herus_phot.csv", lambda L: L)
+    run("herus_noUL", lambda: D.readfluxes_DLC_2014(herus, UL25=False, getArp220=False))
+    run("herus_noUL_keep157", lambda: D.readfluxes_DLC_2014(herus, UL25=False, getArp220=False, del157=False))
+
+    def rows_with_25(L):
+        hdr = L[0].rstrip("\n").split(",")
+        i25, e25 = hdr.index("F25_Jy"), hdr.index("E25_Jy")
+        keep = [L[0]]
+        for ln in L[1:]:
+            c = ln.rstrip("\n").split(",")
+            if len(c) > e25 and c[i25] != "" and c[e25] != "" and float(c[e25]) > 0:
+                keep.append(ln)
+        return keep
+    herus25 = excerpt("dat/herus_phot.csv", "herus_phot_with25.csv", rows_with_25)
+    run("herus_UL", lambda: D.readfluxes_DLC_2014(herus25, UL25=True, getArp220=False))
+    magdis = excerpt("dat/magdis_ulirgs.dat", "magdis_ulirgs.dat", lambda L: L)
+    try:
+        run("magdis_noUL", lambda: D.readfluxes_DLC_2014(magdis, UL25=False, getArp220=False))
+    except Exception as e:                                 # whitespace branch reads bytes under Py3
+        print("  reference readfluxes_DLC_2014 on the whitespace table:", type(e).__name__, e)
+
+    def topcat_rows(L):
+        first = next(i for i, ln in enumerate(L) if ln.startswith("+-"))
+        return L[:first + 3 + 80] + [L[-1]]
+    top = excerpt("dat/ercsc_iifscz.txt", "ercsc_topcat.txt", topcat_rows)
+    run("topcat", lambda: D.readfluxes_ERCSC_TopCat(top))
+    run("topcat_noUL", lambda: D.readfluxes_ERCSC_TopCat(top, upperlim=0))
+
+    peel = excerpt("M31/pixelfit.dat", "peel_pixelfit.dat", lambda L: L[:16])
+    run("peel", lambda: D.readfluxes_peel(peel))
+    run("peel_delnu", lambda: D.readfluxes_peel(peel, delnu=[1763, 12000]))
+    run("dlc3", lambda: D.readfluxes_DLC(peel, format=3, delnu=1763))
+    m31 = excerpt("M31/M31Flux-v2.dat", "M31Flux-v2.dat", lambda L: L)
+    run("m31", lambda: D.readfluxes_M31(m31))
+    run("m31_delnu", lambda: D.readfluxes_M31(m31, delnu=[28.4, 857.0]))
+
+    mdir = os.path.join(cat, "mortier")
+    os.makedirs(mdir, exist_ok=True)
+    names = sorted(os.listdir(os.path.join(src, "dat", "print_seds_mergers")))[:6]
+    for n in names:
+        excerpt(os.path.join("dat", "print_seds_mergers", n), os.path.join("mortier", n), lambda L: L)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = sorted(D.readfluxes_mortier(mdir), key=lambda d: d.name)
+    _pack_datasets("mortier", ds, out)
+
+    out["ref_sha"] = np.array(ref_tree_sha())
+    np.savez_compressed(os.path.join(OUT, "readers_g7.npz"), **out)
+    print("G7 readers:", sorted({k.split("/")[0] for k in out if "/" in k}))
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -714,6 +826,8 @@ def main():
         golden_cl(R)
     if "beam" in which:
         golden_beam(R)
+    if "readers" in which:
+        golden_readers(R)
 
 
 if __name__ == "__main__":
