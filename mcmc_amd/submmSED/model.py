@@ -42,6 +42,26 @@ def _model_engine(model_id):
     return eng
 
 
+def _greybody_host(beta, T, nu, nu_norm=False):
+    """Integrand of totalflux only (post-processing of a finished fit, adaptive quadrature on the
+    host; the likelihood path never comes here).  model.py:97-111"""
+    x = h_over_k * nu / T
+    with np.errstate(over="ignore"):
+        if nu_norm:
+            return (nu / nu_norm) ** (3 + beta) * np.expm1(h_over_k * nu_norm / T) / np.expm1(x)
+        return prefac * nu_b ** (-beta) * nu ** (3 + beta) / np.expm1(x)
+
+
+def totalflux(beta, T, nu1=None, nu2=None, nu_norm=False):
+    """Total flux of a greybody over (nu1, nu2) in GHz, or the analytic bolometric value of the
+    un-normalised greybody when no limits are given.  model.py:113-127"""
+    from scipy import integrate, special
+    if nu1 is None and nu2 is None:
+        return prefac * nu_b ** (-beta) * (T / h_over_k) ** (4 + beta) * \
+            special.gamma(4 + beta) * special.zeta(4 + beta, 1)
+    return integrate.quad(lambda nu: _greybody_host(beta, T, nu, nu_norm=nu_norm), nu1, nu2)[0]
+
+
 def startfrom_generic(start, stds, posidx=(), random=True):   # model.py:63-64
     return start
 
@@ -156,6 +176,11 @@ class submmModel2_normalized(_SedModel):
         super().__init__(A1, b1, T1, A2, b2, T2)
         self.A1, self.b1, self.T1, self.A2, self.b2, self.T2 = A1, b1, T1, A2, b2, T2
 
+    def flux(self, nu1=None, nu2=None):                   # model.py:401-404
+        """flux between the given frequencies for each component"""
+        return np.asarray([self.A1 * totalflux(self.b1, self.T1, nu1, nu2, nu_norm=nu_b),
+                           self.A2 * totalflux(self.b2, self.T2, nu1, nu2, nu_norm=nu_b)])
+
 
 @_finish
 class submmModel2_normalized_logA(_SedModel):
@@ -171,6 +196,8 @@ class submmModel2_normalized_logA(_SedModel):
         self.A1, self.A2 = 10.0 ** logA1, 10.0 ** logA2
         self.b1, self.T1, self.b2, self.T2 = b1, T1, b2, T2
 
+    flux = submmModel2_normalized.flux                    # inherited in the reference
+
 
 @_finish
 class submmModel1_normalized(_SedModel):
@@ -184,6 +211,12 @@ class submmModel1_normalized(_SedModel):
         super().__init__(A, b, T)
         self.A, self.b, self.T = A, b, T
 
+    def flux(self, nu1=None, nu2=None):                   # model.py:555-557
+        """As the reference: integrates the UN-normalised greybody (no nu_norm), although the
+        amplitude is defined at nu_b ("at least one of these is printed incorrectly",
+        driver.py:526)."""
+        return np.array([self.A * totalflux(self.b, self.T, nu1, nu2)])
+
 
 @_finish
 class submmModel1_normalized_logA(_SedModel):
@@ -196,6 +229,8 @@ class submmModel1_normalized_logA(_SedModel):
     def __init__(self, logA, b, T):
         super().__init__(logA, b, T)
         self.A, self.b, self.T = 10.0 ** logA, b, T
+
+    flux = submmModel1_normalized.flux                    # inherited in the reference
 
 
 @_finish
@@ -212,6 +247,9 @@ class submmModel1_opticallythick(_SedModel):
         super().__init__(A, b, T, nu_0)
         self.A, self.b, self.T, self.nu_0 = A, b, T, nu_0
 
+    def flux(self, nu1=None, nu2=None):                   # model.py:669-671 (optically thin integrand)
+        return np.array([self.A * totalflux(self.b, self.T, nu1, nu2, nu_norm=nu_b)])
+
 
 @_finish
 class submmModel1_opticallythick_logA(_SedModel):
@@ -227,6 +265,8 @@ class submmModel1_opticallythick_logA(_SedModel):
     def __init__(self, logA, b, T, nu_0):
         super().__init__(logA, b, T, nu_0)
         self.A, self.b, self.T, self.nu_0 = 10.0 ** logA, b, T, nu_0
+
+    flux = submmModel1_normalized.flux                    # derives from submmModel1_normalized
 
 
 MODEL_CLASSES = [submmModel1_normalized, submmModel1_normalized_logA, submmModel2_normalized,

@@ -810,6 +810,24 @@ def golden_readers(R):
         ds = sorted(D.readfluxes_mortier(mdir), key=lambda d: d.name)
     _pack_datasets("mortier", ds, out)
 
+    # model.flux / totalflux (model.py:113-127 and the flux() methods), what driver.main stores
+    # per object as MLmod.flux(nu1, nu2) with nu1, nu2 = 299792/1000, 299792/8 GHz (driver.py:83-84)
+    M = R["submmSED.model"]
+    nu2, nu1 = 299792. / 8.0, 299792. / 1000.0
+    rng = np.random.default_rng(77)
+    for cls in (M.submmModel2_normalized, M.submmModel2_normalized_logA, M.submmModel1_normalized,
+                M.submmModel1_normalized_logA, M.submmModel1_opticallythick,
+                M.submmModel1_opticallythick_logA):
+        th = []
+        for _ in range(4):
+            comp = lambda: [rng.uniform(0.1, 2.0), rng.uniform(0.5, 2.5), rng.uniform(8.0, 60.0)]
+            t = comp() + comp() if cls.nparam == 6 else comp() + ([rng.uniform(0.5, 3.0)] if cls.nparam == 4 else [])
+            th.append(t)
+        th = np.array(th)
+        out["flux/%s/theta" % cls.__name__] = th
+        out["flux/%s/band" % cls.__name__] = np.array([cls(*t).flux(nu1, nu2) for t in th])
+        out["flux/%s/bolo" % cls.__name__] = np.array([cls(*t).flux() for t in th])
+
     out["ref_sha"] = np.array(ref_tree_sha())
     np.savez_compressed(os.path.join(OUT, "readers_g7.npz"), **out)
     print("G7 readers:", sorted({k.split("/")[0] for k in out if "/" in k}))

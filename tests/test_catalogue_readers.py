@@ -123,3 +123,18 @@ def test_catalogue_arrays_ragged():
     for s, x in enumerate(ds):
         assert np.array_equal(nu[s, :nb[s]], x.freq) and np.array_equal(d[s, :nb[s]], x.d)
         assert np.all(sig[s, nb[s]:] == 1.0) and np.all(d[s, nb[s]:] == 0.0)
+
+
+def test_model_flux_matches_reference():
+    """model.flux(nu1, nu2) / flux() (model.py:113-127 and the per-class flux methods, quirks
+    included: the one-component classes integrate the un-normalised greybody)."""
+    from mcmc_amd.submmSED import model as M
+    nu2, nu1 = 299792. / 8.0, 299792. / 1000.0
+    for cls in (M.submmModel2_normalized, M.submmModel2_normalized_logA, M.submmModel1_normalized,
+                M.submmModel1_normalized_logA, M.submmModel1_opticallythick,
+                M.submmModel1_opticallythick_logA):
+        th = G["flux/%s/theta" % cls.__name__]
+        band = np.array([cls(*t).flux(nu1, nu2) for t in th])
+        bolo = np.array([cls(*t).flux() for t in th])
+        np.testing.assert_allclose(band, G["flux/%s/band" % cls.__name__], rtol=1e-12)
+        np.testing.assert_allclose(bolo, G["flux/%s/bolo" % cls.__name__], rtol=1e-12)
