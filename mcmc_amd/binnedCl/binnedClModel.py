@@ -123,3 +123,100 @@ class binnedClModel(object):
     proposal = Proposal.GenericGaussianProposal(package=package, unpackage=unpackage)
     unpackage = staticmethod(unpackage)
     package = staticmethod(package)
+
+
+# ---------------------------------------------------------------------------------------------
+# post-fit products (host-side, on the samples of a finished chain).  binnedClModel.py:329-503
+# ---------------------------------------------------------------------------------------------
+class oln(object):
+    """offset-lognormal description of the samples C of one band power: z = ln(C + x) Gaussian
+    with mean zbar and variance sigz2.  :329-387"""
+
+    def __init__(self, C):
+        self.C = C
+
+    def chi2(self, zbar, sigz2, x):
+        return ((np.log(self.C + x) / zbar - 1) ** 2).mean() * zbar ** 2 / sigz2
+
+    @staticmethod
+    def like1(par, C):
+        zbar, sigz2, x = par
+        return (np.log(2 * np.pi * sigz2) + (np.log(C + x) / zbar - 1) ** 2 * zbar ** 2 / sigz2 +
+                2 * np.log(C + x))
+
+    def like(self, par):
+        """-2 ln P(par | samples); inf outside sigz2 > 0, C + x > 0"""
+        zbar, sigz2, x = par
+        if sigz2 < 0 or x + min(self.C) < 0:
+            return np.inf
+        return np.log(2 * np.pi * sigz2) + self.chi2(zbar, sigz2, x) + 2 * (np.log(self.C + x)).mean()
+
+    def derivs(self, par):
+        zbar, sigz2, x = par
+        lz = np.log(self.C + x)
+        return np.array([(1.0 / sigz2) * (1.0 - self.chi2(zbar, sigz2, x)),
+                         (2.0 / sigz2) * (zbar - lz.mean()),
+                         (2.0 / sigz2) * ((lz - zbar) / (self.C + x)).mean() + (2.0 / (self.C + x)).mean()])
+
+    def cum(self, par, bins=None):
+        """cumulative distribution at `bins` (default: the sorted samples; a scalar = bin width)"""
+        from scipy import special
+        zbar, sigz2, x = par
+        if bins is None:
+            bins = np.sort(self.C)
+        elif np.isscalar(bins):
+            bins = np.arange(self.C.min(), self.C.max(), bins)
+        s = math.sqrt(2 * sigz2)
+        return 0.5 * (special.erf((zbar - np.log(x)) / s) - special.erf((zbar - np.log(bins + x)) / s))
+
+    def KSnorm(self, par):
+        return max(abs(self.cum(par) - np.linspace(0, 1, len(self.C))))
+
+
+def _oln_start(samples):
+    x_0 = 1.1 * abs(min(samples))
+    lz = np.log(samples + x_0)
+    zbar_0 = lz.mean()
+    return np.array([zbar_0, ((lz - zbar_0) ** 2).mean(), x_0])
+
+
+def fitOffsetLognormal_cum(samples, full_output=0, do_plot=0, verbose=False):
+    """(zbar, sigz2, x) minimising the Kolmogorov-Smirnov distance between the cumulative sample
+    distribution and the offset lognormal (Nelder-Mead, the reference's tolerances).  :390-420
+    Plotting is not rebuilt."""
+    from scipy import optimize
+    o = oln(samples)
+    par_0 = _oln_start(samples)
+    f = optimize.fmin(o.KSnorm, par_0, maxfun=100000, maxiter=100000, xtol=0.00001, ftol=0.00001,
+                      disp=verbose)
+    return f
+
+
+fitOffsetLognormal = fitOffsetLognormal_cum                          # :422
+
+
+def fitOffsetLognormal_like(samples, full_output=0):
+    """maximum-likelihood offset lognormal with L-BFGS-B and analytic derivatives; returns
+    scipy's (x, f, info) triple.  :424-450"""
+    from scipy import optimize
+    o = oln(samples)
+    return optimize.fmin_l_bfgs_b(o.like, _oln_start(samples), fprime=o.derivs)
+
+
+def FisherWindows(F, bins=None, isCovar=False):
+    """Effective band-power windows from the inverse covariance F of the bins (isCovar: F is the
+    covariance).  Without bins: W_bb' = F_bb' / F_bb.  With bins (per spectrum lists of (lmin,
+    lmax)): W[B, spectrum, l] = F_Bb / (lmax_b - lmin_b) / F_BB for l in bin b.  :454-503"""
+    fish = np.linalg.inv(F) if isCovar else np.asarray(F)
+    nbin = fish.shape[0]
+    if bins is None:
+        return (fish.T / fish.diagonal()).T
+    top = max(np.array(b).max() for b in bins)
+    WBl = np.zeros((nbin, 3, top + 1), dtype=np.float64)
+    for ib in range(nbin):
+        jb = 0
+        for ispec, spec in enumerate(bins):
+            for b in spec:
+                WBl[ib, ispec, b[0]:b[1] + 1] = fish[ib, jb] / (b[1] - b[0]) / fish[ib, ib]
+                jb += 1
+    return WBl

@@ -345,8 +345,10 @@ class Engine:
         for k, d in enumerate(datasets):
             nb = int(d.num_points)
             window = np.asarray(d.window, dtype=np.float64)
+            if window.ndim == 3 and window.shape[:2] == (nb, 1):      # TT-only file data (ncls = 1)
+                window = np.concatenate((window, np.zeros((nb, 2, window.shape[2]))), axis=1)
             if window.ndim != 3 or window.shape[0] != nb or window.shape[1] != 3:
-                raise ValueError("window must be [num_points, 3, lmax+1]")
+                raise ValueError("window must be [num_points, 3, lmax+1] (or [num_points, 1, lmax+1])")
             corr = bool(getattr(d, "has_corr_errors", getattr(d, "N_inv", None) is not None))
             e = arr[k]
             e.num_points, e.win_len = nb, window.shape[2]

@@ -834,9 +834,193 @@ def golden_readers(R):
 
 
 
+# ---------------------------------------------------------------------------------------------
+# G8: ClData file formats (.dataset, .newdat, window files; ClData_CosmoMC.py:85-258,
+# ClData_bcp.py:20-210) and the post-fit products of binnedClModel.py:329-503.  The reference
+# ships no such data files (dat/data_list.txt points at an absent data/ tree), so the input files
+# are synthetic, written here into tests/golden/clfiles/; the .npz holds what the reference's
+# parsers make of them.  Py2 `string.split/lower/upper` are given back to the string module
+# (attribute shims, no arithmetic).
+# ---------------------------------------------------------------------------------------------
+def _write_windows(wdir, name, first, bands, ncls, rng, bare_l=False):
+    os.makedirs(wdir, exist_ok=True)
+    for k, (lo, hi) in enumerate(bands):
+        with open(os.path.join(wdir, "%s%d" % (name, first + k)), "w") as f:
+            for l in range(max(lo - 3, 1), hi + 4):
+                w = [np.exp(-0.5 * ((l - 0.5 * (lo + hi)) / (0.3 * (hi - lo) + 2)) ** 2) / (l if not bare_l else 1.0)]
+                if ncls == 3:
+                    w += [0.1 * w[0] * rng.uniform(-1, 1), 0.2 * w[0] * rng.uniform(0, 1)]
+                f.write("%d %s\n" % (l, " ".join("%.10e" % x for x in w)))
+            f.write("%d %s\n" % (lmax_plus(), " ".join("0.0" for _ in range(ncls))))
+
+
+def lmax_plus():
+    return 3600                                            # a line beyond lmax = 3500: ignored
+
+
+def _spd(n, rng, scale):
+    A = rng.standard_normal((n, n))
+    M = A @ A.T / n + np.eye(n)
+    d = np.sqrt(np.diag(M))
+    return M / np.outer(d, d) * np.outer(scale, scale)
+
+
+def golden_clfiles(R):
+    import contextlib
+    import io
+    import string
+    string.split = lambda s, sep=None, maxsplit=-1: s.split(sep, maxsplit)
+    string.lower = lambda s: s.lower()
+    string.upper = lambda s: s.upper()
+    CM = R["ClData.ClData_CosmoMC"]
+    BCP = importlib.import_module("MCMC.ClData.ClData_bcp")
+    root = os.path.join(OUT, "clfiles")
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.default_rng(808)
+    out = {}
+    attrs = ("obs", "var", "sig", "Cl", "err_min", "err_pls", "beam_err", "win_min", "win_max", "ell",
+             "N_inv", "xfactors", "has_xfactor", "inc_pol")
+
+    def pack(prefix, d, Cl):
+        for a in attrs:
+            if hasattr(d, a):
+                out[prefix + "/" + a] = np.asarray(getattr(d, a))
+        w = np.asarray(d.window)
+        out[prefix + "/window_nz"] = np.argwhere(w != 0).astype(np.int32)
+        out[prefix + "/window_val"] = w[w != 0]
+        out[prefix + "/window_shape"] = np.array(w.shape)
+        out[prefix + "/scalars"] = np.array([d.num_points, d.ncls, float(d.calib_uncertainty),
+                                             float(bool(d.beam_uncertain)), float(bool(d.has_pol)),
+                                             float(bool(d.has_xfactors)), float(bool(d.has_corr_errors))])
+        out[prefix + "/name"] = np.array(d.name)
+        out[prefix + "/Clpol_idx"] = np.array(sorted((k, v[0], v[1]) for k, v in d.Clpol_idx.items()), dtype=str)
+        out[prefix + "/Cl_in"] = Cl
+        with np.errstate(all="ignore"):
+            out[prefix + "/lnlike"] = np.array(d.calcLnLike(Cl))
+            out[prefix + "/bandpowers"] = np.array([d.getWinBandpower(i, Cl) for i in range(d.num_points)])
+
+    ell = np.arange(3501.0)
+    Dl = 5000.0 * np.exp(-((ell - 220.0) / 300.0) ** 2) + 1000.0
+    ClTT = np.zeros(3501)
+    ClTT[2:] = Dl[2:] * 2 * np.pi / (ell[2:] * (ell[2:] + 1))
+    Cl3 = np.array([ClTT, 0.05 * ClTT, 0.02 * ClTT])
+
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        # A: .dataset, TT, correlated errors, x-factors, beam + calibration uncertainty
+        bands = [(50 + 60 * k, 100 + 60 * k) for k in range(6)]
+        _write_windows("winA", "expA", 1, bands, 1, rng)
+        obs = np.array([Dl[(lo + hi) // 2] for lo, hi in bands]) * rng.uniform(0.9, 1.1, 6)
+        err = 0.08 * obs
+        x = 0.3 * obs
+        Nz = np.linalg.inv(_spd(6, rng, err / (obs + x)))
+        np.savetxt("expA_Ninv.dat", Nz.reshape(-1, 1), fmt="%.17e")
+        np.savetxt("expA_x.dat", x.reshape(-1, 1), fmt="%.17e")
+        with open("expA.dataset", "w") as f:
+            f.write("# synthetic CosmoMC-format data set (tests)\nname = expA\nhas_pol = F\nnum_points = 6\n"
+                    "calib_uncertainty = 0.05\nbeam_uncertainty = T\nwindow_dir = winA\n"
+                    "windows_are_bandpowers = T\nwindows_are_normalized = F\n; a comment\n\n"
+                    "N_inv = expA_Ninv.dat\nxfactors = expA_x.dat\n")
+            for k in range(6):
+                f.write("data%d = %.10e %.10e %.10e %.10e\n" % (k + 1, obs[k], 0.9 * err[k], 1.1 * err[k],
+                                                               0.02 * obs[k] * (k + 1)))
+        with contextlib.redirect_stdout(io.StringIO()):
+            pack("A", CM.ClData_CosmoMC("expA.dataset"), ClTT)
+
+        # B: .dataset, TT, diagonal errors, bare normalised windows, a band sub-range
+        bandsB = [(300 + 100 * k, 380 + 100 * k) for k in range(7)]
+        _write_windows("winB", "expB", 1, bandsB, 1, rng, bare_l=True)
+        obsB = np.array([Dl[(lo + hi) // 2] for lo, hi in bandsB]) * rng.uniform(0.9, 1.1, 7)
+        with open("expB.dataset", "w") as f:
+            f.write("name = expB\nnum_points = 4\nfile_points = 7\nfirst_band = 3\nwindow_dir = winB\n"
+                    "windows_are_bare = T\nwindows_are_normalized = T\ncalib_uncertainty = 0.0\n")
+            for k in range(4):
+                f.write("data%d = %.10e %.10e %.10e\n" % (k + 1, obsB[k + 2], 0.1 * obsB[k + 2], 0.12 * obsB[k + 2]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            pack("B", CM.ClData_CosmoMC("expB.dataset"), ClTT)
+
+        # C / D: .newdat, TT only with per-band x-factor flags; polarised with BAND_SELECTION
+        def write_newdat(fn, name, npol, specs, cal, beam, ilike, cov, selection=None, fisher=False):
+            with open(fn, "w") as f:
+                if fisher:
+                    f.write("FISHER_T_CMB\n")
+                f.write(name + "\n" + " ".join(str(n) for n in npol) + "\n")
+                if selection is not None:
+                    f.write("BAND_SELECTION\n")
+                    for a, b in selection:
+                        f.write("%d %d\n" % (a, b))
+                f.write("%d %.6f %.6f\n" % cal)
+                f.write("%d %.6f %.6f\n" % beam)
+                f.write("%d\n" % ilike)
+                for typ, rows in specs:
+                    f.write(typ + "\n")
+                    for k, r in enumerate(rows):
+                        f.write("%d " % (k + 1) + " ".join("%.10e" % v for v in r[:4]) +
+                                " %d %d" % (r[4], r[5]) + (" %d" % r[6] if ilike > 1 else "") + "\n")
+                    for k in range(len(rows)):
+                        f.write(" ".join("%.3e" % (1.0 if i == k else 0.0) for i in range(len(rows))) + "\n")
+                for row in cov:
+                    f.write(" ".join("%.17e" % v for v in row) + "\n")
+
+        bandsC = [(100 + 80 * k, 170 + 80 * k) for k in range(5)]
+        _write_windows("data/windows", "expC", 1, bandsC, 1, rng)
+        obsC = np.array([Dl[(lo + hi) // 2] for lo, hi in bandsC]) * rng.uniform(0.9, 1.1, 5)
+        rowsC = [(obsC[k], 0.07 * obsC[k], 0.09 * obsC[k], 0.25 * obsC[k], bandsC[k][0], bandsC[k][1], k % 2)
+                 for k in range(5)]
+        write_newdat("expC.newdat", "expC", [5, 0, 0, 0, 0, 0], [("TT", rowsC)], (1, 1.02, 0.04),
+                     (1, 10.0, 0.6), 2, _spd(5, rng, 0.08 * obsC))
+        with contextlib.redirect_stdout(io.StringIO()):
+            pack("C", BCP.ClData_bcp("expC.newdat"), ClTT)
+
+        bTT = [(100 + 100 * k, 190 + 100 * k) for k in range(4)]
+        bEE = [(150 + 150 * k, 290 + 150 * k) for k in range(3)]
+        bTE = [(150 + 150 * k, 290 + 150 * k) for k in range(3)]
+        _write_windows("data/windows", "expD", 1, bTT + bEE + bTE, 3, rng)
+        oTT = np.array([Dl[(lo + hi) // 2] for lo, hi in bTT])
+        oEE = 0.02 * np.array([Dl[(lo + hi) // 2] for lo, hi in bEE])
+        oTE = 0.05 * np.array([Dl[(lo + hi) // 2] for lo, hi in bTE]) * np.array([1, -1, 1])
+        mk = lambda o, b: [(o[k], 0.1 * abs(o[k]), 0.1 * abs(o[k]), 2.0 * abs(o[k]), b[k][0], b[k][1], 1)
+                           for k in range(len(o))]
+        allo = np.concatenate((oTT, oEE, oTE))
+        write_newdat("expD.newdat", "expD", [4, 3, 0, 0, 3, 0],
+                     [("TT", mk(oTT, bTT)), ("EE", mk(oEE, bEE)), ("TE", mk(oTE, bTE))], (1, 0.98, 0.03),
+                     (0, 12.0, 0.5), 1, _spd(10, rng, 0.1 * np.abs(allo)),
+                     selection=[(2, 4), (1, 2), (0, 0), (0, 0), (1, 3), (0, 0)], fisher=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            pack("D", BCP.ClData_bcp("expD.newdat"), Cl3)
+    finally:
+        os.chdir(cwd)
+
+    # post-fit products, binnedClModel.py:329-503
+    BM = R["binnedCl.binnedClModel"]
+    F = _spd(7, rng, rng.uniform(0.5, 2.0, 7))
+    bins = [[(2, 50), (51, 120), (121, 300)], [(2, 100), (101, 300)], [(2, 150), (151, 300)]]
+    out["post/F"] = F
+    out["post/Wbb"] = BM.FisherWindows(F)
+    out["post/Wbb_covar"] = BM.FisherWindows(F, isCovar=True)
+    out["post/WBl"] = BM.FisherWindows(F, bins=bins)
+    samp = np.exp(rng.normal(5.0, 0.3, 4000)) - 40.0
+    out["post/samples"] = samp
+    with contextlib.redirect_stdout(io.StringIO()):
+        out["post/oln_cum"] = np.asarray(BM.fitOffsetLognormal_cum(samp, do_plot=0))
+        fl = BM.fitOffsetLognormal_like(samp)
+    out["post/oln_like_x"] = np.asarray(fl[0])
+    out["post/oln_like_f"] = np.asarray(fl[1])
+    o = BM.oln(samp)
+    par = np.array([5.0, 0.1, 45.0])
+    out["post/oln_par"] = par
+    out["post/oln_eval"] = np.array([o.chi2(*par), o.like(par), o.KSnorm(par)] + list(o.derivs(par)))
+    out["post/oln_cumcurve"] = o.cum(par)
+    out["ref_sha"] = np.array(ref_tree_sha())
+    np.savez_compressed(os.path.join(OUT, "clfiles_g8.npz"), **out)
+    print("G8 clfiles:", sorted({k.split("/")[0] for k in out if "/" in k}))
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam", "readers"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -846,6 +1030,8 @@ def main():
         golden_beam(R)
     if "readers" in which:
         golden_readers(R)
+    if "clfiles" in which:
+        golden_clfiles(R)
 
 
 if __name__ == "__main__":
