@@ -796,9 +796,10 @@ int mi355_mh_ess(mi355_ctx* c, double* ess) {
   const int P = c->mhP;
   const int64_t n = c->mhS * P;
   if (c->scratch_a.alloc(static_cast<size_t>(n))) return -2;
-  int nt = 64;
-  while (nt < c->C) nt <<= 1;
-  const size_t lds = (static_cast<size_t>(c->nkeep) * nt + nt) * sizeof(double);
+  int ntc_shift = 6;                                      // chain slots per block: 64, 128 or 256
+  while ((1 << ntc_shift) < c->C) ++ntc_shift;
+  const int nt = 1 << ntc_shift;
+  const size_t lds = (static_cast<size_t>(c->nkeep) * nt + 4 * kEssLags) * sizeof(double);
   static size_t opted = 0;
   if (lds > 48 * 1024 && lds > opted) {
     MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ess),
@@ -806,8 +807,8 @@ int mi355_mh_ess(mi355_ctx* c, double* ess) {
     opted = lds;
   }
   MI355_REQUIRE(lds <= 150 * 1024, "mi355_mh_ess: trace tile (%zu B) does not fit in LDS", lds);
-  hipLaunchKernelGGL(k_ess, dim3(static_cast<unsigned>(n)), dim3(nt), lds, c->stream, P, c->mhS, c->C,
-                     c->N, static_cast<int>(c->nkeep), c->tr_theta.p, c->scratch_a.p);
+  hipLaunchKernelGGL(k_ess, dim3(static_cast<unsigned>(n)), dim3(256), lds, c->stream, P, c->mhS, c->C,
+                     c->N, static_cast<int>(c->nkeep), ntc_shift, c->tr_theta.p, c->scratch_a.p);
   MI355_HIP(hipGetLastError());
   std::vector<double> h(static_cast<size_t>(n));
   MI355_HIP(hipMemcpyAsync(h.data(), c->scratch_a.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -494,41 +494,51 @@ __global__ void k_gelman_rubin(int nchain, int P, const double* __restrict__ mea
 //   n_eff = m n / (1 + 2 sum_t rho_t),  rho_t = 1 - V_t / (2 var+),
 //   V_t = sum_j sum_i (x_ij - x_(i-t)j)^2 / (m (n - t)),  var+ = (n-1)/n W + B/n,
 // the sum running over t = 1, 2, ... until rho_(t+1) + rho_(t+2) < 0 at an odd t (or the lags
-// run out).  One block per (group, parameter); thread j owns chain j (C <= blockDim.x) and keeps
-// its n <= kEssMaxRows trace values in LDS.
+// run out).  One block of 256 threads per (group, parameter): thread = (chain j, lag group g),
+// ntc = 2^ntc_shift >= C chain slots, G = 256/ntc lag groups.  The n <= kEssMaxRows trace values
+// of every chain sit in LDS; a thread evaluates four consecutive lags per pass over its chain with
+// a sliding window (two LDS reads serve four lags), the sum over chains is a wave shuffle
+// reduction, and the stopping rule is applied once per batch of 4 G lags.
 constexpr int kEssMaxRows = 128;
+constexpr int kEssLags = 4;
 
-__global__ __launch_bounds__(256) void k_ess(int P, int64_t S, int C, int64_t N, int nrows,
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_ess(int P, int64_t S, int C, int64_t N, int nrows, int ntc_shift,
                                              const double* __restrict__ trace /*[nrows][P][N]*/,
                                              double* __restrict__ ess /*[P][S]*/) {
-  extern __shared__ double sh[];                       // [nrows][blockDim.x] + reduction scratch
+  extern __shared__ double sh[];                       // x[nrows][ntc] + red[4 waves][kEssLags]
   const int64_t s = blockIdx.x / P;
   const int p = static_cast<int>(blockIdx.x % P);
-  const int j = threadIdx.x, nt = blockDim.x;
+  const int ntc = 1 << ntc_shift, G = 256 >> ntc_shift;
+  const int tid = threadIdx.x, j = tid & (ntc - 1), g = tid >> ntc_shift;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wpg = ntc >> 6;                            // waves per lag group
   double* x = sh;
-  double* red = sh + static_cast<size_t>(nrows) * nt;
+  double* red = sh + static_cast<size_t>(nrows) * ntc;
   const bool live = j < C;
+  for (int i = g; i < nrows; i += G)
+    x[i * ntc + j] = live ? trace[(static_cast<int64_t>(i) * P + p) * N + s * C + j] : 0.0;
+  __syncthreads();
   double sum = 0.0;
-  for (int i = 0; i < nrows; ++i) {
-    const double v = live ? trace[(static_cast<int64_t>(i) * P + p) * N + s * C + j] : 0.0;
-    x[i * nt + j] = v;
-    sum += v;
-  }
+  for (int i = 0; i < nrows; ++i) sum += x[i * ntc + j];
   const double mean_j = sum / nrows;
   double ss = 0.0;
   for (int i = 0; i < nrows; ++i) {
-    const double dlt = x[i * nt + j] - mean_j;
+    const double dlt = x[i * ntc + j] - mean_j;
     ss += dlt * dlt;
   }
+  // sum over the chains (group 0 holds one copy of each)
   auto block_sum = [&](double v) -> double {
+    const double w = wave_sum((live && g == 0) ? v : 0.0);
     __syncthreads();
-    red[j] = live ? v : 0.0;
+    if (lane == 0) red[wave] = w;
     __syncthreads();
-    for (int off = nt >> 1; off > 0; off >>= 1) {
-      if (j < off) red[j] += red[j + off];
-      __syncthreads();
-    }
-    return red[0];
+    return red[0] + red[1] + red[2] + red[3];
   };
   const double m = static_cast<double>(C), n = static_cast<double>(nrows);
   const double W = block_sum(ss / (n - 1.0)) / m;                  // mean within-chain variance
@@ -537,28 +547,55 @@ __global__ __launch_bounds__(256) void k_ess(int P, int64_t S, int C, int64_t N,
   const double B_over_n = (C > 1) ? block_sum(dm * dm) / (m - 1.0) : 0.0;
   const double varplus = (n - 1.0) / n * W + B_over_n;
   double rho_sum = 0.0, prev = 0.0;
-  bool have_prev = false;
-  if (varplus > 0.0) {
-    for (int t = 1; t < nrows; ++t) {
+  bool have_prev = false, done = !(varplus > 0.0);
+  for (int t0 = 1; t0 < nrows && !done; t0 += G * kEssLags) {
+    const int tb = t0 + g * kEssLags;                  // lags tb .. tb+3 of this thread's chain
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int i = tb; i < nrows; ++i) {
+      const double xi = x[i * ntc + j], a0 = x[(i - tb) * ntc + j];
+      const int k = i - tb;                            // wave-uniform
+      double d = xi - a0;
+      v0 += d * d;
+      if (k >= 1) { d = xi - a1; v1 += d * d; }
+      if (k >= 2) { d = xi - a2; v2 += d * d; }
+      if (k >= 3) { d = xi - a3; v3 += d * d; }
+      a3 = a2;
+      a2 = a1;
+      a1 = a0;
+    }
+    if (!live) v0 = v1 = v2 = v3 = 0.0;
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    v3 = wave_sum(v3);
+    __syncthreads();                                   // red of the previous batch has been read
+    if (lane == 0) {
+      red[wave * kEssLags + 0] = v0;
+      red[wave * kEssLags + 1] = v1;
+      red[wave * kEssLags + 2] = v2;
+      red[wave * kEssLags + 3] = v3;
+    }
+    __syncthreads();
+    for (int q = 0; q < G * kEssLags; ++q) {           // every thread applies the same rule
+      const int t = t0 + q;
+      if (t >= nrows) { done = true; break; }
+      const int gq = q / kEssLags, u = q % kEssLags;
       double v = 0.0;
-      for (int i = t; i < nrows; ++i) {
-        const double dlt = x[i * nt + j] - x[(i - t) * nt + j];
-        v += dlt * dlt;
-      }
-      const double Vt = block_sum(v) / (m * (n - t));
+      for (int w = 0; w < wpg; ++w) v += red[(gq * wpg + w) * kEssLags + u];
+      const double Vt = v / (m * (n - t));
       const double rho = 1.0 - Vt / (2.0 * varplus);
       // pairs (rho_1, rho_2), (rho_3, rho_4), ...: stop at the first pair with a negative sum
       if (!have_prev) {
         prev = rho;
         have_prev = true;
       } else {
-        if (prev + rho < 0.0) break;
+        if (prev + rho < 0.0) { done = true; break; }
         rho_sum += prev + rho;
         have_prev = false;
       }
     }
   }
-  if (j == 0) ess[p * S + s] = (varplus > 0.0) ? m * n / (1.0 + 2.0 * rho_sum) : __builtin_nan("");
+  if (tid == 0) ess[p * S + s] = (varplus > 0.0) ? m * n / (1.0 + 2.0 * rho_sum) : __builtin_nan("");
 }
 
 __global__ void k_scale(int64_t n, double f, double* x) {

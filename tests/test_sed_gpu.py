@@ -231,23 +231,25 @@ def test_free_running_chains_match_oracle(eng, mid, do_block):
             assert mom["naccept"][s, c] == ch.naccept
 
 
-def test_ess_matches_bda3_restatement():
+@pytest.mark.parametrize("C,nrows", [(64, 100), (40, 37), (100, 128), (256, 50), (2, 9)])
+def test_ess_matches_bda3_restatement(C, nrows):
     """mi355_mh_ess (no reference counterpart: BASELINE.json's ESS/s) against the numpy
-    restatement of the same estimator on the same trace."""
+    restatement of the same estimator on the same trace; chain counts on either side of the
+    64 / 128 / 256 slot layouts and row counts that are not multiples of the lag batch."""
     from mcmc_amd import Engine, synth
-    S, C = 6, 64
+    S = 6
     nu, d, sig, _ = synth.sed_catalogue(S, seed=21)
     with Engine(seed=77) as eng:
         eng.sed_load("M2N", np.full(S, 8, np.int32), nu, d, sig)
         eng.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6))
         eng.mh_run(600)
         eng.mh_adapt()
-        eng.mh_run(1200, thin=12)
-        tr, _, _ = eng.mh_trace()                       # [100, S, C, 6]
+        eng.mh_run(12 * nrows, thin=12)
+        tr, _, _ = eng.mh_trace()                       # [nrows, S, C, 6]
         ess = eng.mh_ess()
-    assert ess.shape == (S, 6)
+    assert ess.shape == (S, 6) and tr.shape[0] == nrows
     for s in range(S):
         for p in range(6):
             ref = R.ess_bda3(tr[:, s, :, p])
             assert abs(ess[s, p] - ref) <= 1e-9 * abs(ref), (s, p, ess[s, p], ref)
-    assert np.all(ess > 1.0) and np.all(ess <= 100 * C * 1.5)
+    assert np.all(ess > 0.5) and np.all(ess <= nrows * C * 1.5)
