@@ -20,6 +20,7 @@ namespace mi355 {
 
 constexpr int kBeamCH = 8;       // chains per register group
 constexpr int kBeamNC = 12;      // constants per chain in LDS
+constexpr int kBeamNF = 9;       // folded constants of the fast pixel loop
 
 // Per-chain constants of the model from PACKAGED parameters.
 //  k[0..1] centre, k[2..4] Cxx, Cyy, Cxy, k[5] amplitude, k[6] offset, k[7] plane factor
@@ -63,6 +64,65 @@ __device__ __forceinline__ double beam_model_at(const double* k, double x, doubl
   return k[5] * v;
 }
 
+// Folded constants for the pixel loop: the factor -1/2 of the exponent goes into C^-1 and the
+// plane factor into its direction cosines, so that a pixel costs 5 FMA-class operations for the
+// exponent, 3 for offset + plane and 1 for the residual (the reference's operation order, kept in
+// beam_model_at, costs 22).  The reassociation moves a model value by a few ulp, far inside the
+// 1e-12 budget of lnL (tests/test_beam_gpu.py).
+// The exponent is produced directly in base 2 (the folded C^-1 carries log2 e), so the
+// exponential needs no argument scaling: 2^y = 2^n (1 + P(y - n)), P = expm1(f ln 2) as one
+// degree-12 Horner chain whose coefficients are those of fastmath.hpp's expm1_reduced times
+// ln2^k.
+//  f[0..1] centre, f[2] -Cxx/2 log2e, f[3] -Cyy/2 log2e, f[4] -Cxy log2e, f[5] offset,
+//  f[6..7] plane gradient, f[8] amplitude
+__device__ __forceinline__ void beam_fold(const double* k, double* f) {
+  f[0] = k[0];
+  f[1] = k[1];
+  f[2] = -0.5 * k[2] * kLog2e;
+  f[3] = -0.5 * k[3] * kLog2e;
+  f[4] = -k[4] * kLog2e;
+  f[5] = k[6];
+  const bool plane = k[10] != 0.0;
+  f[6] = plane ? k[7] * k[8] : 0.0;
+  f[7] = plane ? k[7] * k[9] : 0.0;
+  f[8] = k[5];
+}
+
+// 2^y for y <= ~1000 (no upper clamp: the exponent of a positive-definite form is <= 0)
+__device__ __forceinline__ double exp2_nonpos(double y) {
+  y = fmax(y, -1080.0);
+  const double fn = rint(y);
+  const double f = y - fn;                                           // exact, |f| <= 1/2
+  double p = 0x1.c499cfddcaf42p-36;
+  p = fma(p, f, 0x1.e9e10f65f7b9ep-32);
+  p = fma(p, f, 0x1.e4cf178358319p-28);
+  p = fma(p, f, 0x1.b524f4346fe3bp-24);
+  p = fma(p, f, 0x1.62c02240ffc75p-20);
+  p = fma(p, f, 0x1.ffcbfc694e0cfp-17);
+  p = fma(p, f, 0x1.430912f86bd94p-13);
+  p = fma(p, f, 0x1.5d87fe78a4e11p-10);
+  p = fma(p, f, 0x1.3b2ab6fba4e78p-7);
+  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = fma(p, f, 0x1.ebfbdff82c58fp-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  return ldexp(fma(p, f, 1.0), static_cast<int>(fn));
+}
+
+template <bool WPIX>
+__device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], double x, double y,
+                                                double dv, double w, double* acc) {
+#pragma unroll
+  for (int c = 0; c < kBeamCH; ++c) {
+    const double dx = x - f[c][0], dy = y - f[c][1];
+    const double u = fma(f[c][4], dy, f[c][2] * dx);
+    const double arg = fma(dx, u, (f[c][3] * dy) * dy);
+    const double g = exp2_nonpos(arg);
+    const double v = fma(dx, f[c][6], fma(dy, f[c][7], g + f[c][5]));
+    const double r = fma(-f[c][8], v, dv);
+    acc[c] = WPIX ? fma(r * w, r, acc[c]) : fma(r, r, acc[c]);
+  }
+}
+
 struct BeamArgs {
   const double* x;        // [npix] or [M][npix]
   const double* y;
@@ -82,6 +142,7 @@ struct BeamArgs {
 
 __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
   __shared__ double kc[kBeamCH][kBeamNC];
+  __shared__ double fc[kBeamCH][kBeamNF];
   __shared__ double red[4][kBeamCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t ml = blockIdx.y;                       // map within this call
@@ -104,6 +165,10 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < kBeamNC; ++i) kc[tid][i] = k[i];
+    double f[kBeamNF];
+    beam_fold(k, f);
+#pragma unroll
+    for (int i = 0; i < kBeamNF; ++i) fc[tid][i] = f[i];
   }
   __syncthreads();
   bool irregular = false;
@@ -119,16 +184,18 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
 #pragma unroll
   for (int c = 0; c < kBeamCH; ++c) acc[c] = 0.0;
   const double w_shared = (a.w_kind == 2) ? 0.0 : ws[0];
-  for (int64_t p = p0 + tid; p < p1; p += 256) {
-    const double x = xs[p], y = ys[p], dv = ds[p];
-    const double w = (a.w_kind == 2) ? ws[p] : w_shared;
-    if (!irregular) {
+  if (!irregular && a.w_kind == 2) {
+    for (int64_t p = p0 + tid; p < p1; p += 256)
+      beam_pixel_fast<true>(fc, xs[p], ys[p], ds[p], ws[p], acc);   // GaussianData.py:47
+  } else if (!irregular) {
+    for (int64_t p = p0 + tid; p < p1; p += 256)                    // one weight: taken out of the sum
+      beam_pixel_fast<false>(fc, xs[p], ys[p], ds[p], 0.0, acc);
 #pragma unroll
-      for (int c = 0; c < kBeamCH; ++c) {
-        const double r = dv - beam_model_at<false>(kc[c], x, y);
-        acc[c] = fma(r * w, r, acc[c]);                             // GaussianData.py:47
-      }
-    } else {
+    for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
+  } else {
+    for (int64_t p = p0 + tid; p < p1; p += 256) {
+      const double x = xs[p], y = ys[p], dv = ds[p];
+      const double w = (a.w_kind == 2) ? ws[p] : w_shared;
 #pragma unroll
       for (int c = 0; c < kBeamCH; ++c) {
         const double r = dv - beam_model_at<true>(kc[c], x, y);
