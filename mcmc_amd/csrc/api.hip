@@ -289,8 +289,8 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
   c->P = m->nparam;
   c->S = S;
   c->nbm = nb_max;
-  auto dd_log = [](double v, double* hi, double* lo) {   // ln(v) as hi + lo (x87 80-bit logl)
-    const long double l = logl(static_cast<long double>(v));
+  auto dd_log = [](double v, double* hi, double* lo) {   // log2(v) as hi + lo (x87 80-bit log2l)
+    const long double l = log2l(static_cast<long double>(v));
     *hi = static_cast<double>(l);
     *lo = static_cast<double>(l - static_cast<long double>(*hi));
   };
@@ -312,7 +312,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
       o[2 * nb_max + j] = v / m->nu_b;           // nu/nu_norm            model.py:109
       o[3 * nb_max + j] = live ? d[s * nb_max + j] : 0.0;
       o[4 * nb_max + j] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
-      // ln of the band's power-law base (the rounded double the reference raises to 3+beta)
+      // log2 of the band's power-law base (the rounded double the reference raises to 3+beta)
       dd_log(base_is_nu ? v : v / m->nu_b, &o[5 * nb_max + j], &o[6 * nb_max + j]);
       if (live)
         MI355_REQUIRE(v > 0.0 && std::isfinite(v) && std::fabs(o[5 * nb_max + j]) < 100.0,
@@ -321,7 +321,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     }
   }
   // The fast kernels run without argument clamps: allow them only if, over the whole prior box,
-  // every Planck argument h nu/kT and every power-law exponent (3+beta) ln(base) stays below 300
+  // every Planck argument h nu/kT and every power-law exponent (3+beta) log2(base) stays below 300
   // (products of two such exponentials still fit a double); otherwise the exact OCML path runs.
   {
     const double emax = std::fmax(std::fabs(3.0 + m->bmin), std::fabs(3.0 + m->bmax));
@@ -721,7 +721,7 @@ int mi355_gauss_quadform(mi355_ctx* c, int64_t m, int64_t n, const double* A, co
 int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* cc, double* out) {
   MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
-  MI355_REQUIRE(fn >= 0 && fn <= 7, "mi355_math_probe: unknown function %d", fn);
+  MI355_REQUIRE(fn >= 0 && fn <= 8, "mi355_math_probe: unknown function %d", fn);
   MI355_REQUIRE((fn != 2 && fn != 3) || b, "mi355_math_probe: b required");
   MI355_REQUIRE(fn != 2 || cc, "mi355_math_probe: c required");
   MI355_HIP(hipSetDevice(c->device));

@@ -78,7 +78,7 @@ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct SedConsts {
   double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
-  double ln_nub_hi, ln_nub_lo;   // ln(nu_b) as a double-double
+  double ln_nub_hi, ln_nub_lo;   // log2(nu_b) as a double-double
   double fast_ok;  // 1: every band keeps the fast kernels' arguments in range over the prior box
 };
 

@@ -68,6 +68,33 @@ __device__ __forceinline__ double pow_prelog(double e, double lhi, double llo) {
 
 __device__ __forceinline__ double exp10_fast(double x) { return pow_prelog<true>(x, kLn10Hi, kLn10Lo); }
 
+// (2^f - 1)/f for |f| <= 1/2 (+ a small low part): the coefficients of expm1_reduced times ln2^k,
+// so that a power whose logarithm is stored in base 2 needs no argument scaling at all.
+__device__ __forceinline__ double exp2m1_over_f(double f) {
+  double p = 0x1.c499cfddcaf42p-36;
+  p = fma(p, f, 0x1.e9e10f65f7b9ep-32);
+  p = fma(p, f, 0x1.e4cf178358319p-28);
+  p = fma(p, f, 0x1.b524f4346fe3bp-24);
+  p = fma(p, f, 0x1.62c02240ffc75p-20);
+  p = fma(p, f, 0x1.ffcbfc694e0cfp-17);
+  p = fma(p, f, 0x1.430912f86bd94p-13);
+  p = fma(p, f, 0x1.5d87fe78a4e11p-10);
+  p = fma(p, f, 0x1.3b2ab6fba4e78p-7);
+  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
+  p = fma(p, f, 0x1.ebfbdff82c58fp-3);
+  return fma(p, f, 0x1.62e42fefa39efp-1);
+}
+
+// base^e with log2(base) = l2hi + l2lo known to double-double precision, |e log2(base)| < 1000
+// (the caller bounds it: SedConsts::fast_ok).  Three instructions fewer than pow_prelog.
+__device__ __forceinline__ double pow2_prelog(double e, double l2hi, double l2lo) {
+  const double p = e * l2hi;
+  const double pe = fma(e, l2hi, -p);      // exact low part of the product
+  const double fn = rint(p);
+  const double f = (p - fn) + fma(e, l2lo, pe);
+  return ldexp(fma(exp2m1_over_f(f), f, 1.0), static_cast<int>(fn));
+}
+
 // expm1(x), any finite x (clamped to [-40, kExpMax]: below -40 the result is -1 to the last bit):
 //   2^n (1+q) - 1 = 2^n * (q + (1 - 2^-n)),  q = expm1(r); the inner sum is exact-ish (one
 //   rounding), so there is no cancellation for any n.

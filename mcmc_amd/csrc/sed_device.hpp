@@ -21,7 +21,7 @@ struct Bands {
   __device__ __forceinline__ double ratio(int j) const { return base[2 * nbm + j]; }  // nu / nu_b
   __device__ __forceinline__ double d(int j) const { return base[3 * nbm + j]; }
   __device__ __forceinline__ double w(int j) const { return base[4 * nbm + j]; }      // 1/sig^2
-  // ln(base) = lhi + llo of the band's power-law base: nu/nu_b for the normalised models,
+  // log2(base) = lhi + llo of the band's power-law base: nu/nu_b for the normalised models,
   // nu for submmModel1/2 (set per catalogue by mi355_sed_load)
   __device__ __forceinline__ double lhi(int j) const { return base[5 * nbm + j]; }
   __device__ __forceinline__ double llo(int j) const { return base[6 * nbm + j]; }
@@ -123,7 +123,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pow_prelog<false>(e3, B.lhi(j), B.llo(j)) * en, expm1_fast<false>(x));
+      const double g = div_fast(pow2_prelog(e3, B.lhi(j), B.llo(j)) * en, expm1_fast<false>(x));
       const double r = B.d(j) - A * g;
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -140,20 +140,20 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
-      const double g1 = div_fast(pow_prelog<false>(e1, lh, ll) * en1, expm1_fast<false>(div_rcp(hn, T1, rT1)));
-      const double g2 = div_fast(pow_prelog<false>(e2, lh, ll) * en2, expm1_fast<false>(div_rcp(hn, T2, rT2)));
+      const double g1 = div_fast(pow2_prelog(e1, lh, ll) * en1, expm1_fast<false>(div_rcp(hn, T1, rT1)));
+      const double g2 = div_fast(pow2_prelog(e2, lh, ll) * en2, expm1_fast<false>(div_rcp(hn, T2, rT2)));
       const double r = B.d(j) - fma(A2, g2, A1 * g1);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
   } else if constexpr (MODEL == MI355_SED_M1) {
     const double T = th[1], e3 = 3.0 + th[0];
-    const double pre = k.prefac * pow_prelog<false>(-th[0], k.ln_nub_hi, k.ln_nub_lo);
+    const double pre = k.prefac * pow2_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
     const double rT = 1.0 / T;
     double FNiF = 0.0, FNid = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pre * pow_prelog<false>(e3, B.lhi(j), B.llo(j)), expm1_fast<false>(x));
+      const double g = div_fast(pre * pow2_prelog(e3, B.lhi(j), B.llo(j)), expm1_fast<false>(x));
       const double gw = g * B.w(j);
       FNiF = fma(gw, g, FNiF);
       FNid = fma(gw, B.d(j), FNid);

@@ -386,6 +386,7 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
     case 5: v = log_fast(a[i]); break;
     case 6: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = sn; break; }
     case 7: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = cs; break; }
+    case 8: v = pow2_prelog(a[i], b[i], c[i]); break;
     default: v = exp10_fast(a[i]); break;
   }
   out[i] = v;

@@ -70,6 +70,15 @@ def test_pow_with_precomputed_log(eng):
                 [mp.power(mp.mpf(float(b)), mp.mpf(float(x))) for b, x in zip(base, e)])
     print("pow: max %.2f ulp" % w)
     assert w <= 1.5
+    # the base-2 variant the SED fast path uses (log2 of the base stored as a double-double)
+    for i, b in enumerate(base):
+        l = mp.log(mp.mpf(float(b)), 2)
+        lhi[i] = float(l)
+        llo[i] = float(l - mp.mpf(lhi[i]))
+    w = ulp_err(eng.math_probe(8, e, lhi, llo),
+                [mp.power(mp.mpf(float(b)), mp.mpf(float(x))) for b, x in zip(base, e)])
+    print("pow2: max %.2f ulp" % w)
+    assert w <= 1.5
 
 
 def test_newton_division(eng):
