@@ -131,8 +131,9 @@ def main():
     eng.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                 randomize_start=True)
     # stage 0 with the production driver's proposal widths, then newMCMC(): sigma = 2.4/sqrt(6)*stdev
-    eng.mh_run(args.adapt)
-    eng.mh_adapt()
+    if args.adapt > 0:
+        eng.mh_run(args.adapt)
+        eng.mh_adapt()
 
     def one_step():
         eng.mh_run(inner)

@@ -71,8 +71,7 @@ __device__ __forceinline__ double beam_model_at(const double* k, double x, doubl
 // 1e-12 budget of lnL (tests/test_beam_gpu.py).
 // The exponent is produced directly in base 2 (the folded C^-1 carries log2 e), so the
 // exponential needs no argument scaling: 2^y = 2^n (1 + P(y - n)), P = expm1(f ln 2) as one
-// degree-12 Horner chain whose coefficients are those of fastmath.hpp's expm1_reduced times
-// ln2^k.
+// degree-11 Horner chain (fastmath.hpp: exp2m1_over_f).
 //  f[0..1] centre, f[2] -Cxx/2 log2e, f[3] -Cyy/2 log2e, f[4] -Cxy log2e, f[5] offset,
 //  f[6..7] plane gradient, f[8] amplitude
 __device__ __forceinline__ void beam_fold(const double* k, double* f) {
@@ -93,18 +92,7 @@ __device__ __forceinline__ double exp2_nonpos(double y) {
   y = fmax(y, -1080.0);
   const double fn = rint(y);
   const double f = y - fn;                                           // exact, |f| <= 1/2
-  double p = 0x1.c499cfddcaf42p-36;
-  p = fma(p, f, 0x1.e9e10f65f7b9ep-32);
-  p = fma(p, f, 0x1.e4cf178358319p-28);
-  p = fma(p, f, 0x1.b524f4346fe3bp-24);
-  p = fma(p, f, 0x1.62c02240ffc75p-20);
-  p = fma(p, f, 0x1.ffcbfc694e0cfp-17);
-  p = fma(p, f, 0x1.430912f86bd94p-13);
-  p = fma(p, f, 0x1.5d87fe78a4e11p-10);
-  p = fma(p, f, 0x1.3b2ab6fba4e78p-7);
-  p = fma(p, f, 0x1.c6b08d704a0c2p-5);
-  p = fma(p, f, 0x1.ebfbdff82c58fp-3);
-  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  const double p = exp2m1_over_f(f);
   return ldexp(fma(p, f, 1.0), static_cast<int>(fn));
 }
 

@@ -135,14 +135,17 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double T1 = th[2], T2 = th[5];
     const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
     const double rT1 = 1.0 / T1, rT2 = 1.0 / T2;
-    const double en1 = expm1_fast<false>(div_rcp(k.hk_nub, T1, rT1));
-    const double en2 = expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
+    // A_c expm1(x_b,c) is a per-component constant; the two components of a band share one
+    // division: A1 g1 + A2 g2 = (n1 d2 + n2 d1) / (d1 d2), d_c = expm1(h nu / k T_c) < e^300 each
+    // (fast_ok), so the product of two stays finite
+    const double ae1 = A1 * expm1_fast<false>(div_rcp(k.hk_nub, T1, rT1));
+    const double ae2 = A2 * expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
-      const double g1 = div_fast(pow2_prelog(e1, lh, ll) * en1, expm1_fast<false>(div_rcp(hn, T1, rT1)));
-      const double g2 = div_fast(pow2_prelog(e2, lh, ll) * en2, expm1_fast<false>(div_rcp(hn, T2, rT2)));
-      const double r = B.d(j) - fma(A2, g2, A1 * g1);
+      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = expm1_fast<false>(div_rcp(hn, T1, rT1));
+      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = expm1_fast<false>(div_rcp(hn, T2, rT2));
+      const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;

@@ -233,6 +233,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 #ifndef MI355_MH_MIN_WAVES
 #define MI355_MH_MIN_WAVES 2
 #endif
+#ifndef MI355_ABL
+#define MI355_ABL 0       // timing ablations of tools/ablate.sh (never set in the product build)
+#endif
 template <int MODEL, bool FAST>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   constexpr int P = ModelTraits<MODEL>::P;
@@ -246,7 +249,11 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
+#if MI355_ABL == 3
+  Bands B{smem + (s - s_first) * stride, a.nbm, 0};
+#else
   Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s]};
+#endif
 
   double th[P], sg[P], mu[P], m2[P];
   uint32_t accb[P];
@@ -283,10 +290,14 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       u = a.inj_u[t * a.N + n];
     } else {
       if (a.npn == 1) {
+#if MI355_ABL == 2
+        za = 0.3; zb = -0.2; ua = 0.4; ub = 0.6;
+#else
         if (t == 0 || (step & 1u) == 0) {
           philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
           philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
         }
+#endif
         const double z = (step & 1u) ? zb : za;
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -313,7 +324,11 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       if (!bad) {
         if (prior != 1.0) v += log(prior);                 // :250
         const double lnalpha = v - lnPr;                   // :251 (+ lndensityRatio = 0, :252)
+#if MI355_ABL == 4
+        const bool reject = !(lnalpha >= 0.0) && !(1.0 + lnalpha > u);
+#else
         const bool reject = !(lnalpha >= 0.0) && !(exp_fast(lnalpha) > u);   // :264
+#endif
         if (!reject) {
           accepted = true;
           next = v;
@@ -331,6 +346,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     if (a.nblock) blk = (blk + 1 == a.nblock) ? 0 : blk + 1;   // :278-279
 
     // running ddof=0 moments over every appended sample (mean/stdev with burn=1, :290-307)
+#if MI355_ABL != 1
     const double rn = rcp_nr(static_cast<double>(a.nsamp0 + t + 1));   // 1/n to 2^-50
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       mu[i] += dlt * rn;
       m2[i] += dlt * (th[i] - mu[i]);
     }
+#endif
     if (a.thin > 0) {
       if (++thin_ctr == a.thin) {
         thin_ctr = 0;
