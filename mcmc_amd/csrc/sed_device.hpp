@@ -143,8 +143,8 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
-      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = expm1_fast<false>(div_rcp(hn, T1, rT1));
-      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = expm1_fast<false>(div_rcp(hn, T2, rT2));
+      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = expm1_fast<false>(hn * rT1);
+      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = expm1_fast<false>(hn * rT2);
       const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
