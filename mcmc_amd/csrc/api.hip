@@ -314,6 +314,8 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
       o[4 * nb_max + j] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
       // log2 of the band's power-law base (the rounded double the reference raises to 3+beta)
       dd_log(base_is_nu ? v : v / m->nu_b, &o[5 * nb_max + j], &o[6 * nb_max + j]);
+      o[7 * nb_max + j] = static_cast<double>(static_cast<long double>(o[1 * nb_max + j]) *
+                                              1.442695040888963407359924681001892137L);
       if (live)
         MI355_REQUIRE(v > 0.0 && std::isfinite(v) && std::fabs(o[5 * nb_max + j]) < 100.0,
                       "source %lld band %d: frequency %g GHz out of range",

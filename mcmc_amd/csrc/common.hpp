@@ -63,7 +63,7 @@ struct DevBuf {
 };
 
 constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
-constexpr int kBandFields = 7;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, ln(base) hi, lo
+constexpr int kBandFields = 8;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, log2(base) hi, lo, h/k*nu*log2(e)
 constexpr int kBlockThreads = 256;
 
 struct ClProblem;     // cl_api.hip

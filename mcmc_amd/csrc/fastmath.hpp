@@ -107,6 +107,17 @@ __device__ __forceinline__ double expm1_fast(double x) {
   return ldexp(q + t, n);
 }
 
+// 2^y - 1 for 0 <= y < 1000 (the Planck argument h nu / kT in units of ln 2; the caller bounds
+// it: SedConsts::fast_ok): same composition as expm1_fast, no argument scaling.
+__device__ __forceinline__ double exp2m1_fast(double y) {
+  const double fn = rint(y);
+  const double f = y - fn;                  // exact
+  const int n = static_cast<int>(fn);
+  const double q = exp2m1_over_f(f) * f;
+  const double t = 1.0 - ldexp(1.0, -n);
+  return ldexp(q + t, n);
+}
+
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.

@@ -25,6 +25,8 @@ struct Bands {
   // nu for submmModel1/2 (set per catalogue by mi355_sed_load)
   __device__ __forceinline__ double lhi(int j) const { return base[5 * nbm + j]; }
   __device__ __forceinline__ double llo(int j) const { return base[6 * nbm + j]; }
+  // h nu / k in units of ln 2: the Planck argument of the fast path comes out in base 2
+  __device__ __forceinline__ double hnu2(int j) const { return base[7 * nbm + j]; }
 };
 
 template <int MODEL>
@@ -142,9 +144,9 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double ae2 = A2 * expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
-      const double hn = B.hnu(j), lh = B.lhi(j), ll = B.llo(j);
-      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = expm1_fast<false>(hn * rT1);
-      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = expm1_fast<false>(hn * rT2);
+      const double hn = B.hnu2(j), lh = B.lhi(j), ll = B.llo(j);
+      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = exp2m1_fast(hn * rT1);
+      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = exp2m1_fast(hn * rT2);
       const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
