@@ -118,6 +118,13 @@ __device__ __forceinline__ double exp2m1_fast(double y) {
   return ldexp(q + t, n);
 }
 
+// 2^(y + extra), |y| < 1000 (bounded by the caller), |extra| << 1
+__device__ __forceinline__ double exp2_fast(double y, double extra) {
+  const double fn = rint(y);
+  const double f = (y - fn) + extra;
+  return ldexp(fma(exp2m1_over_f(f), f, 1.0), static_cast<int>(fn));
+}
+
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.

@@ -137,16 +137,21 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double T1 = th[2], T2 = th[5];
     const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
     const double rT1 = 1.0 / T1, rT2 = 1.0 / T2;
-    // A_c expm1(x_b,c) is a per-component constant; the two components of a band share one
-    // division: A1 g1 + A2 g2 = (n1 d2 + n2 d1) / (d1 d2), d_c = expm1(h nu / k T_c) < e^300 each
-    // (fast_ok), so the product of two stays finite
+    // Per band and component, with y = h nu / (k T ln 2) and a = (3+beta) log2(nu/nu_b):
+    //   A r^(3+beta) expm1(x_b) / expm1(x) = [A expm1(x_b)] 2^(a-y) / (1 - 2^-y),
+    // two plain 2^z kernels and a subtraction instead of a power and an expm1 (1 - 2^-y loses
+    // log2(1/x) bits, x >= 1e-3 is part of fast_ok); the exponent a - y is one FMA on the high
+    // part of log2(nu/nu_b) (its rounding, |a - y| 2^-53 in the result, is the error that
+    // matters; tools/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
+    // share one division, (n1 d2 + n2 d1) / (d1 d2) with d in (0, 1].
     const double ae1 = A1 * expm1_fast<false>(div_rcp(k.hk_nub, T1, rT1));
     const double ae2 = A2 * expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
-      const double hn = B.hnu2(j), lh = B.lhi(j), ll = B.llo(j);
-      const double n1 = pow2_prelog(e1, lh, ll) * ae1, d1 = exp2m1_fast(hn * rT1);
-      const double n2 = pow2_prelog(e2, lh, ll) * ae2, d2 = exp2m1_fast(hn * rT2);
+      const double hn = B.hnu2(j), lh = B.lhi(j);
+      const double y1 = hn * rT1, y2 = hn * rT2;
+      const double n1 = exp2_fast(fma(e1, lh, -y1), 0.0) * ae1, d1 = 1.0 - exp2_fast(-y1, 0.0);
+      const double n2 = exp2_fast(fma(e2, lh, -y2), 0.0) * ae2, d2 = 1.0 - exp2_fast(-y2, 0.0);
       const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
