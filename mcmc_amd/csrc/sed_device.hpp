@@ -121,12 +121,13 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double A = (MODEL == MI355_SED_M1N) ? th[0] : exp10_fast(th[0]);
     const double T = th[2], e3 = 3.0 + th[1];
     const double rT = 1.0 / T;
-    const double en = expm1_fast<false>(div_rcp(k.hk_nub, T, rT));
+    // same base-2 form of the band term as the two-component branch below
+    const double ae = A * expm1_fast<false>(div_rcp(k.hk_nub, T, rT));
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
-      const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pow2_prelog(e3, B.lhi(j), B.llo(j)) * en, expm1_fast<false>(x));
-      const double r = B.d(j) - A * g;
+      const double y = B.hnu2(j) * rT;
+      const double n = exp2_fast(fma(e3, B.lhi(j), -y), 0.0) * ae, dn = 1.0 - exp2_fast(-y, 0.0);
+      const double r = B.d(j) - div_fast(n, dn);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
@@ -162,8 +163,8 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double rT = 1.0 / T;
     double FNiF = 0.0, FNid = 0.0;
     for (int j = 0; j < B.nb; ++j) {
-      const double x = div_rcp(B.hnu(j), T, rT);
-      const double g = div_fast(pre * pow2_prelog(e3, B.lhi(j), B.llo(j)), expm1_fast<false>(x));
+      const double y = B.hnu2(j) * rT;                      // base is nu itself for this model
+      const double g = div_fast(pre * exp2_fast(fma(e3, B.lhi(j), -y), 0.0), 1.0 - exp2_fast(-y, 0.0));
       const double gw = g * B.w(j);
       FNiF = fma(gw, g, FNiF);
       FNid = fma(gw, B.d(j), FNid);
