@@ -110,15 +110,31 @@ def fit_catalogue(datasets, mod, like_cls=None, start=None, sigmas=None, nMC=nMC
     eng.sed_load(mod.model_id, nb, nu, d, sg, consts=model.device_constants())
     eng.mh_init(nchains, start, sigmas, param_blocks=np.asarray(mod.paramBlocks, np.int32),
                 randomize_start=True)                      # doBlock=True, driver.py:173-175
+    params = np.where(sigmas > 0)[0]
+    resampled = []
+
+    def stuck_chains():
+        """chains whose stage statistics are unusable: max(stdev/mean) < 1e-9 over the sampled
+        parameters, the test of sampler() (MCMC.py:549-560)"""
+        m = eng.mh_moments()
+        with np.errstate(all="ignore"):
+            ratio = np.sqrt(m["var"][..., params]) / m["mean"][..., params]
+        return int(np.sum(np.nanmax(ratio, axis=-1) < 1.e-9))
+
     for n in nMC[:-1]:
+        # A stage is repeated (appended to) while it produced no usable statistics, at most ten
+        # times in all (nresample_max, MCMC.py:491).  One launch serves every chain, so all
+        # chains of the catalogue get the extra steps, not only the stuck ones.
         eng.mh_run(int(n))
+        while len(resampled) < 10 and stuck_chains() > 0:
+            resampled.append(int(n))
+            eng.mh_run(int(n))
         eng.mh_adapt(fac=fac, random_restart=randomrestart)
     n_last = int(nMC[-1])
     thin = max(1, -(-n_last // max_rows))                  # <= max_rows rows (mi355_mh_ess takes 128)
     eng.mh_run(n_last, thin=thin)
     mom = eng.mh_moments()
     samples, lnPr, _ = eng.mh_trace()
-    params = np.where(sigmas > 0)[0]
     burn_rows = int(burn * samples.shape[0])               # histgrid(burn=0.2), driver.py:182-184
     mean, std, ncov, maxlnL, mlpar = _pooled_stats(mom, samples, lnPr, params, burn_rows)
     # package() as MCMC.mean()/stdev() apply it (MCMC.py:297,311)
@@ -142,7 +158,7 @@ def fit_catalogue(datasets, mod, like_cls=None, start=None, sigmas=None, nMC=nMC
         rec += (float(-2.0 * lnl_ml[s]) if not marginalised else float("nan"),)
         records.append(rec)
     diag = dict(rhat=eng.rhat(), ess=eng.mh_ess(), accept_rate=mom["naccept"] / float(eng.nsamples + 1),
-                thin=thin)
+                thin=thin, resampled=resampled)
     if return_engine:
         return records, diag, eng
     eng.close()

@@ -54,3 +54,18 @@ def test_main_reads_selects_and_fits(tmp_path):
     assert [b[2] for b in back] == [r[2] for r in recs]
     one = drv.main(f, i=2, filetype="MRR", nMC=(300, 600), nchains=8, linear=True)
     assert isinstance(one, tuple) and len(one) == 7
+
+
+def test_stage_is_repeated_while_chains_have_not_moved():
+    """sampler()'s retry (MCMC.py:549-560): a stage whose chains produced no usable statistics is
+    run again, up to ten times."""
+    from mcmc_amd.submmSED import data as D, driver as drv, model as M
+    ds = D.readfluxes_DLC_2014(os.path.join(CAT, "herus_phot.csv"), UL25=False, getArp220=False)[:6]
+    # two steps with enormous proposal widths: practically no chain moves in the first stage
+    recs, diag = drv.fit_catalogue(ds, M.submmModel1_normalized, start=(1., 2., 10.),
+                                   sigmas=(5., 8., 100.), nMC=(2, 400, 800), nchains=16, seed=3)
+    assert 1 <= len(diag["resampled"]) <= 10 and diag["resampled"][0] == 2
+    assert all(np.all(r[0][1] > 0) for r in recs)         # every object ends with usable statistics
+    recs2, diag2 = drv.fit_catalogue(ds, M.submmModel1_normalized, start=(1., 2., 10.),
+                                     sigmas=(2., 4., 4.), nMC=(300, 600), nchains=16, seed=3)
+    assert diag2["resampled"] == []
