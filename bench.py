@@ -120,6 +120,7 @@ def main():
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()                 # (rehearsals: more ranks than GPUs)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

@@ -28,10 +28,13 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MI355_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs
+            # than ranks (gloo stages CUDA tensors through the host)
+            backend = os.environ.get("MI355_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
