@@ -86,7 +86,11 @@ static FormPlan plan_for(const ClData* d) {
 }
 
 static size_t form_lds_bytes(int nbp, int TR, int NW = 8) {
-  return (static_cast<size_t>(nbp) * TR + NW * TR * 3) * sizeof(double) + 2 * TR * sizeof(int);
+  // row tile + reduction scratch (at least 16 rows of it: the row fragments are fetched up to
+  // four k-steps past the tile) + row tables
+  const size_t red = static_cast<size_t>(NW) * TR * 3 > static_cast<size_t>(16) * TR
+                         ? static_cast<size_t>(NW) * TR * 3 : static_cast<size_t>(16) * TR;
+  return (static_cast<size_t>(nbp) * TR + red) * sizeof(double) + 2 * TR * sizeof(int);
 }
 
 template <int RT, int CG, int MODE, int NW, bool SYM = false>
@@ -292,7 +296,8 @@ int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
       for (int r = 0; r < nb; ++r)
         std::memcpy(&pad[static_cast<size_t>(r) * nbp], s.N_inv + static_cast<size_t>(r) * nb,
                     nb * sizeof(double));
-      if (upload(c, d->ninv, pad.data(), pad.size())) return -2;
+      // 16 zero rows beyond the matrix: k_cl_form fetches its fragments four k-steps ahead
+      if (upload(c, d->ninv, pad.data(), pad.size(), pad.size() + static_cast<size_t>(16) * nbp)) return -2;
       // block-upper symmetrised copy for the diagonal forms (k_cl_form SYM): one rounding per
       // off-diagonal entry, none at all when N^-1 is exactly symmetric
       sym.assign(pad.size(), 0.0);
@@ -304,7 +309,7 @@ int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
             sym[static_cast<size_t>(r) * nbp + q] =
                 pad[static_cast<size_t>(r) * nbp + q] + pad[static_cast<size_t>(q) * nbp + r];
         }
-      if (upload(c, d->nsym, sym.data(), sym.size())) return -2;
+      if (upload(c, d->nsym, sym.data(), sym.size(), sym.size() + static_cast<size_t>(16) * nbp)) return -2;
     } else {
       pad.assign(static_cast<size_t>(nbp), 1.0);
       std::memcpy(pad.data(), s.var, nb * sizeof(double));

@@ -97,8 +97,8 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 // of Y = V.N^-1 -> ct = w, w+NW, ..., CG of them per pass.  Eight waves put two on every SIMD, so
 // the row staging (a long dependent chain per element: ln) and the MFMA stream of one wave fill
 // the stalls of the other.  V is staged band-major in LDS (vt[k][TR]); N^-1
-// fragments come straight from L2 (the matrix is shared by every block) and are fetched one
-// k-step ahead of the MFMAs that use them.  MFMA operand maps (cdna_hip_programming.md
+// fragments come straight from L2 (the matrix is shared by every block) and are fetched four
+// k-steps ahead of the MFMAs that use them.  MFMA operand maps (cdna_hip_programming.md
 // sect. 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D col = l&15, row = (l>>4) + 4*reg.
 // MODE (ClFormMode) is a template parameter so that the row-staging loop is specialised; the
 // TRIPLE mode keeps three dot products per Y row (NT = 3), the others one.  waves-per-EU >= 2 in
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
   extern __shared__ double smem[];
   double* vt = smem;                                       // [nbp][TR]
   double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [NW][TR][3]
-  int* rowc = reinterpret_cast<int*>(red + NW * TR * 3);   // [TR] chain of each row
+  int* rowc = reinterpret_cast<int*>(red + (NW * 3 > 16 ? NW * 3 : 16) * TR);   // [TR] chain of each row
   int* rows = rowc + TR;                                   // [TR] sub-index of each row
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
@@ -205,38 +205,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
       nb_ptr[j] = nmat + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
     }
     const double* va_ptr = vt + lk * TR + lc;
-    // ping-pong operand registers, each set fetched one k-step before the MFMAs that read it;
-    // the scheduling barriers keep the compiler from sinking the fetches next to their use
-    double a0[RT], b0[CG], a1[RT], b1[CG];
+    // Software pipeline: the matrix fragments (L2, ~600 cycles away) are fetched FOUR k-steps
+    // ahead into a ring of registers, the row fragments (LDS) one k-step ahead; the scheduling
+    // barriers keep the compiler from sinking the fetches next to their use.  The fetches run
+    // up to four k-steps past the end: the matrix is allocated with 16 zero rows of slack and
+    // the row tile is followed by the reduction scratch in LDS, and nothing read there is used.
+    double av[2][RT], bv[4][CG];
+    const double* bp[CG];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a0[rt] = va_ptr[rt * 16];
+    for (int j = 0; j < CG; ++j) {
 #pragma unroll
-    for (int j = 0; j < CG; ++j) b0[j] = nb_ptr[j][0];
+      for (int u = 0; u < 4; ++u) bv[u][j] = nb_ptr[j][u * kstride];
+      bp[j] = nb_ptr[j] + 4 * kstride;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) av[0][rt] = va_ptr[rt * 16];
+    const double* ap = va_ptr + 4 * TR;
     const int ksteps = SYM ? (ct0 + 1) * 4 : a.nbp >> 2;   // a multiple of 4
-    for (int ks = 0; ks < ksteps; ks += 2) {
+    for (int ks = 0; ks < ksteps; ks += 4) {
 #pragma unroll
-      for (int j = 0; j < CG; ++j) b1[j] = nb_ptr[j][(ks + 1) * kstride];
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a1[rt] = va_ptr[(ks + 1) * 4 * TR + rt * 16];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int rt = 0; rt < RT; ++rt) av[(u + 1) & 1][rt] = ap[rt * 16];
+        ap += 4 * TR;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < CG; ++j)
+        for (int j = 0; j < CG; ++j)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[rt], b0[j], acc[rt][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const int kn = (ks + 2 < ksteps) ? ks + 2 : ks;      // the last pair refetches itself
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u & 1][rt], bv[u][j], acc[rt][j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < CG; ++j) b0[j] = nb_ptr[j][kn * kstride];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a0[rt] = va_ptr[kn * 4 * TR + rt * 16];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < CG; ++j)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[rt], b1[j], acc[rt][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < CG; ++j) {
+          bv[u][j] = bp[j][0];
+          bp[j] += kstride;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // epilogue: Y[row][col] * V[row'][col] summed over this wave's columns
 #pragma unroll
