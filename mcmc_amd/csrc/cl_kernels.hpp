@@ -108,6 +108,9 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 // upper triangle of the symmetrised matrix, sum_J (sum_{I<=J} v_I S_IJ) v_J, which halves the
 // MFMA work; column tiles are dealt to the waves in snake order so that every wave gets the same
 // number of k-steps.
+#ifndef MI355_CL_ABL
+#define MI355_CL_ABL 0     // timing ablations (never set in the product build)
+#endif
 template <int RT, int CG, int MODE, int NW, bool SYM>
 __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
   static_assert(!SYM || (CG == 1 && MODE != CL_ROWS_TRIPLE), "SYM needs CG == 1 and a diagonal form");
@@ -136,34 +139,54 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
     const int r = tid % TR;                                // TR is a power of two
     const int c = rowc[r], sub = rows[r];
     constexpr bool marge = MODE == CL_ROWS_MARGE;
+    // no marginalisation over one of the two: the centre point of its grid, whose factor is
+    // exactly 1 (the beam-factor table always exists; multiplying by 1.0 changes nothing)
     double calib = 1.0;
-    const double* bf = nullptr;
+    const double* bf = a.bfac + static_cast<size_t>(kClHalfSteps) * a.nbp;
     if (marge && c >= 0) {
       if (a.ncal > 1) calib = 1.0 + a.calib * (sub % a.ncal - kClHalfSteps) * 3 / kClHalfSteps;   // :337
       if (a.nbeam > 1) bf = a.bfac + static_cast<size_t>(sub / a.ncal) * a.nbp;                   // :334
     }
-    // nbp is a multiple of 16 and the stride divides 16: the trip count is a multiple of 4, and
-    // four independent iterations in flight hide the L2 latency of the operand loads
+    const bool has_x = a.has_x != 0;
+    constexpr int KS = NTHR / TR;                          // bands between a thread's iterations
+    if constexpr (!marge) {
 #pragma unroll 4
-    for (int k = tid / TR; k < a.nbp; k += NTHR / TR) {
-      // branch-free so that the unrolled iterations interleave (one wave per SIMD: the only
-      // latency hiding there is comes from instruction-level parallelism)
-      const bool live = c >= 0 && k < a.nb;
+      for (int k = tid / TR; k < a.nbp; k += KS) vt[k * TR + r] = cl_row_value(a, c, sub, k);
+    } else {
+      // Four bands per trip: all operand loads first (the tables are padded to nbp, indices
+      // clamped), then the arithmetic, every lane computing the logarithm whether it needs it
+      // or not - a branch around it would put a memory round trip in front of every band.
       const int64_t cc = c >= 0 ? c : 0;
-      double v;
-      if constexpr (!marge) {
-        v = cl_row_value(a, c, sub, k);
-      } else {
-        double b = a.bp[static_cast<int64_t>(k) * a.n + cc];
-        if (bf) b *= bf[k];
-        if (a.ncal > 1) b = calib * b;                     // :338
-        const bool lx = a.has_x && a.hasx[k];              // :383-392
-        double zth = b + a.xf[k];
-        zth = (zth <= 0.0) ? 0.0 : zth;
-        const double t = lx ? cl_log(zth) : b;
-        v = live ? a.obs[k] - t : 0.0;
+      for (int k0 = tid / TR; k0 < a.nbp; k0 += 4 * KS) {
+        double bpv[4], bfv[4], xfv[4], obv[4];
+        uint8_t hx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(k0 + u * KS, a.nbp - 1);
+          bpv[u] = a.bp[static_cast<int64_t>(k) * a.n + cc];
+          bfv[u] = bf[k];
+          xfv[u] = a.xf[k];
+          obv[u] = a.obs[k];
+          hx[u] = a.hasx[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * KS;
+          double b = bpv[u] * bfv[u];                      // :334
+          b = calib * b;                                   // :338
+          double zth = b + xfv[u];                         // :383-392
+          zth = (zth <= 0.0) ? 0.0 : zth;
+#if MI355_CL_ABL == 1
+          double lg = zth;
+#else
+          double lg = cl_log(zth);
+#endif
+          asm volatile("" : "+v"(lg));                     // keep the logarithm out of a branch
+          const double t = (has_x && hx[u]) ? lg : b;
+          const double v = (c >= 0 && k < a.nb) ? obv[u] - t : 0.0;
+          if (k < a.nbp) vt[k * TR + r] = v;
+        }
       }
-      vt[k * TR + r] = v;
     }
   }
   __syncthreads();
@@ -221,7 +244,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) av[0][rt] = va_ptr[rt * 16];
     const double* ap = va_ptr + 4 * TR;
+#if MI355_CL_ABL == 2
+    const int ksteps = 4;
+#else
     const int ksteps = SYM ? (ct0 + 1) * 4 : a.nbp >> 2;   // a multiple of 4
+#endif
     for (int ks = 0; ks < ksteps; ks += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
