@@ -253,3 +253,40 @@ def test_ess_matches_bda3_restatement(C, nrows):
             ref = R.ess_bda3(tr[:, s, :, p])
             assert abs(ess[s, p] - ref) <= 1e-9 * abs(ref), (s, p, ess[s, p], ref)
     assert np.all(ess > 0.5) and np.all(ess <= nrows * C * 1.5)
+
+
+@pytest.mark.parametrize("mid", [R.M1N, R.M2N])
+def test_catalogue_outside_the_fast_path_domain(eng, mid):
+    """The clamp-free base-2 kernels are only used when every band keeps 1e-3 <= h nu/kT over the
+    prior box (and the exponents below 300): a radio point (1.4 GHz: h nu/k Tmax = 7e-4) and a
+    mid-infrared one (h nu/k Tmin > 300) send the whole catalogue through the exact path; same
+    parity bar, and the same sources without those bands agree on the common points."""
+    S, C = 40, 16
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=17)
+    nu2, d2, sig2 = nu.copy(), d.copy(), sig.copy()
+    nu2[:, 0] = 1.4                                   # below the 1 - 2^-y guard
+    nu2[:, 1] = 3.0e4                                 # h nu / k Tmin = 480
+    rng = np.random.default_rng(9)
+    P = R.MODEL_NPARAM[mid]
+    th = truth[:, None, :P] * rng.uniform(0.8, 1.25, (S, C, P))
+    eng.sed_load(mid, np.full(S, 8, np.int32), nu2, d2, sig2)
+    got = eng.sed_lnlike(th)
+    ref = np.array([[R.sed_lnlike(mid, th[s, c], R.GaussData(nu2[s], d2[s], sig2[s])) for c in range(C)]
+                    for s in range(S)])
+    assert_lnl_close(got, ref, RTOL_LNL, "exact path model %d" % mid)
+    # a short chain on that catalogue against the oracle, draw for draw
+    eng.mh_init(2, truth[:, None, :P].repeat(2, axis=1), np.full(P, 0.05), param_blocks=np.arange(P),
+                randomize_start=False)
+    z, u = eng.rng_dump(eng.step_total, 30, S * 2, 1)
+    eng.mh_run(30, thin=1)
+    tr, lp, _ = eng.mh_trace()
+    s, c = 3, 1
+    n = s * 2 + c
+    zz = np.zeros((30, P))
+    for t in range(30):
+        zz[t, t % P] = z[t, n, 0]
+    ch = R.Chain(R.sed_problem(mid, R.GaussData(nu2[s], d2[s], sig2[s])), np.full(P, 0.05), truth[s, :P],
+                 R.InjectedDraws(zz, u[:, n]), do_block=True, randomize_start=False)
+    ch.run(30)
+    np.testing.assert_allclose(tr[:, s, c], np.asarray(ch.samples)[1:], rtol=1e-12)
+    np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
