@@ -803,11 +803,12 @@ int mi355_mh_ess(mi355_ctx* c, double* ess) {
   while ((1 << ntc_shift) < c->C) ++ntc_shift;
   const int nt = 1 << ntc_shift;
   const size_t lds = (static_cast<size_t>(c->nkeep) * nt + 4 * kEssLags) * sizeof(double);
-  static size_t opted = 0;
-  if (lds > 48 * 1024 && lds > opted) {
+  static size_t opted[kMaxDevices] = {};   // per device: the attribute belongs to the device's code object
+  size_t& have = opted[c->device % kMaxDevices];
+  if (lds > 48 * 1024 && lds > have) {
     MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ess),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    opted = lds;
+    have = lds;
   }
   MI355_REQUIRE(lds <= 150 * 1024, "mi355_mh_ess: trace tile (%zu B) does not fit in LDS", lds);
   hipLaunchKernelGGL(k_ess, dim3(static_cast<unsigned>(n)), dim3(256), lds, c->stream, P, c->mhS, c->C,

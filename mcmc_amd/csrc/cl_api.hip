@@ -98,11 +98,13 @@ static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
   constexpr int TR = 16 * RT;
   const int rows_used = (a.mode == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
   const size_t lds = form_lds_bytes(a.nbp, TR, NW);
-  static size_t opted = 0;              // largest dynamic LDS opted in for this instantiation
-  if (lds > 48 * 1024 && lds > opted) {
+  // largest dynamic LDS opted in for this instantiation, per device
+  static size_t opted[kMaxDevices] = {};
+  size_t& have = opted[c->device % kMaxDevices];
+  if (lds > 48 * 1024 && lds > have) {
     MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, MODE, NW, SYM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    opted = lds;
+    have = lds;
   }
   const unsigned grid = static_cast<unsigned>(ceil_div64(a.rows, rows_used));
   hipLaunchKernelGGL((k_cl_form<RT, CG, MODE, NW, SYM>), dim3(grid), dim3(64 * NW), lds, c->stream, a);

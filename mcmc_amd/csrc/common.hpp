@@ -63,6 +63,7 @@ struct DevBuf {
 };
 
 constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
+constexpr int kMaxDevices = 64;  // size of per-device caches of launch attributes
 constexpr int kBandFields = 8;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, log2(base) hi, lo, h/k*nu*log2(e)
 constexpr int kBlockThreads = 256;
 
