@@ -295,7 +295,9 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     *lo = static_cast<double>(l - static_cast<long double>(*hi));
   };
   c->kc = SedConsts{m->h_over_k, m->nu_b, m->prefac, m->Tmin, m->Tmax, m->bmin, m->bmax,
-                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0, 0.0};
+                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0, 0.0, 0.0};
+  c->kc.hk_nub2 = static_cast<double>(static_cast<long double>(c->kc.hk_nub) *
+                                      1.442695040888963407359924681001892137L);
   dd_log(m->nu_b, &c->kc.ln_nub_hi, &c->kc.ln_nub_lo);
   const bool base_is_nu = (m->model == MI355_SED_M1 || m->model == MI355_SED_M2);
   // host-side derived band fields (each rounded once, as the reference computes them)

@@ -81,6 +81,7 @@ struct SedConsts {
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
   double ln_nub_hi, ln_nub_lo;   // log2(nu_b) as a double-double
   double fast_ok;  // 1: every band keeps the fast kernels' arguments in range over the prior box
+  double hk_nub2;  // hk_nub * log2(e): the normalisation argument of the fast path in base 2
 };
 
 }  // namespace mi355

@@ -120,9 +120,9 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
                 MODEL == MI355_SED_THICK_LOGA) {
     const double A = (MODEL == MI355_SED_M1N) ? th[0] : exp10_fast(th[0]);
     const double T = th[2], e3 = 3.0 + th[1];
-    const double rT = 1.0 / T;
+    const double rT = rcp_nr2(T);                          // T >= Tmin > 0 on this path
     // same base-2 form of the band term as the two-component branch below
-    const double ae = A * expm1_fast<false>(div_rcp(k.hk_nub, T, rT));
+    const double ae = A * exp2m1_fast(k.hk_nub2 * rT);
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double y = B.hnu2(j) * rT;
@@ -137,7 +137,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double A2 = lg ? exp10_fast(th[3]) : th[3];
     const double T1 = th[2], T2 = th[5];
     const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
-    const double rT1 = 1.0 / T1, rT2 = 1.0 / T2;
+    const double rT1 = rcp_nr2(T1), rT2 = rcp_nr2(T2);     // T >= Tmin > 0 on this path
     // Per band and component, with y = h nu / (k T ln 2) and a = (3+beta) log2(nu/nu_b):
     //   A r^(3+beta) expm1(x_b) / expm1(x) = [A expm1(x_b)] 2^(a-y) / (1 - 2^-y),
     // two plain 2^z kernels and a subtraction instead of a power and an expm1 (1 - 2^-y loses
@@ -145,8 +145,8 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     // part of log2(nu/nu_b) (its rounding, |a - y| 2^-53 in the result, is the error that
     // matters; tools/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
     // share one division, (n1 d2 + n2 d1) / (d1 d2) with d in (0, 1].
-    const double ae1 = A1 * expm1_fast<false>(div_rcp(k.hk_nub, T1, rT1));
-    const double ae2 = A2 * expm1_fast<false>(div_rcp(k.hk_nub, T2, rT2));
+    const double ae1 = A1 * exp2m1_fast(k.hk_nub2 * rT1);
+    const double ae2 = A2 * exp2m1_fast(k.hk_nub2 * rT2);
     double chi2 = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double hn = B.hnu2(j), lh = B.lhi(j);
