@@ -317,7 +317,10 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     const double prior = sed_prior<MODEL>(nw, a.k);
     bool accepted = false;
     double next = lnPr;
-    if (prior > 0.0 && all_finite<P>(nw)) {
+    // A non-finite proposal inside the prior box (A = inf / NaN: the box has no upper bound on A
+    // and NaN passes every comparison) comes out of the fast kernels as NaN or -inf and is
+    // rejected below like any bad likelihood, so the fast instantiation needs no finiteness test.
+    if (prior > 0.0 && (FAST || all_finite<P>(nw))) {
       double v = FAST ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
                       : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
