@@ -336,7 +336,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
       for (int j = 0; j < nb[s]; ++j) {
         const double* o = h.data() + s * stride;
         if (!(o[1 * nb_max + j] / m->Tmin < 300.0) || !(emax * std::fabs(o[5 * nb_max + j]) < 300.0) ||
-            !(m->Tmax > 0.0 && o[1 * nb_max + j] / m->Tmax >= 1.0e-3)) {
+            !(m->Tmax > 0.0 && o[1 * nb_max + j] / m->Tmax >= 0.02)) {   // 1 - 2^-y keeps >= 47 bits
           ok = false;
           break;
         }

@@ -141,7 +141,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     // Per band and component, with y = h nu / (k T ln 2) and a = (3+beta) log2(nu/nu_b):
     //   A r^(3+beta) expm1(x_b) / expm1(x) = [A expm1(x_b)] 2^(a-y) / (1 - 2^-y),
     // two plain 2^z kernels and a subtraction instead of a power and an expm1 (1 - 2^-y loses
-    // log2(1/x) bits, x >= 1e-3 is part of fast_ok); the exponent a - y is one FMA on the high
+    // log2(1/x) bits, x >= 0.02 is part of fast_ok); the exponent a - y is one FMA on the high
     // part of log2(nu/nu_b) (its rounding, |a - y| 2^-53 in the result, is the error that
     // matters; tools/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
     // share one division, (n1 d2 + n2 d1) / (d1 d2) with d in (0, 1].

@@ -257,7 +257,7 @@ def test_ess_matches_bda3_restatement(C, nrows):
 
 @pytest.mark.parametrize("mid", [R.M1N, R.M2N])
 def test_catalogue_outside_the_fast_path_domain(eng, mid):
-    """The clamp-free base-2 kernels are only used when every band keeps 1e-3 <= h nu/kT over the
+    """The clamp-free base-2 kernels are only used when every band keeps 0.02 <= h nu/kT over the
     prior box (and the exponents below 300): a radio point (1.4 GHz: h nu/k Tmax = 7e-4) and a
     mid-infrared one (h nu/k Tmin > 300) send the whole catalogue through the exact path; same
     parity bar, and the same sources without those bands agree on the common points."""
