@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag>   (run on the GPU box from the repo root)
+# usage: tools/prof_bench.sh <tag>   (run on the GPU box from the repo root)
 set -e
 tag=$1
 cd /tmp && export TMPDIR=/tmp
