@@ -284,7 +284,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
                   static_cast<long long>(s), nb[s], nb_max);
   MI355_HIP(hipSetDevice(c->device));
   c->sed_loaded = false;
-  c->mh_ready = false;
+  mh_invalidate(c);
   c->model = *m;
   c->P = m->nparam;
   c->S = S;

@@ -51,6 +51,7 @@ int mi355_beam_load(mi355_ctx* c, int64_t M, int64_t npix, const double* x, cons
   MI355_REQUIRE(M > 0 && npix > 0, "mi355_beam_load: empty input (M=%lld, npix=%lld)",
                 static_cast<long long>(M), static_cast<long long>(npix));
   MI355_REQUIRE(sig_kind >= 0 && sig_kind <= 2, "mi355_beam_load: sig_kind %d", sig_kind);
+  mh_invalidate(c);
   MI355_HIP(hipSetDevice(c->device));
   auto p = std::make_unique<BeamProblem>();
   p->M = M;

@@ -251,6 +251,7 @@ extern "C" {
 
 int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
   MI355_REQUIRE(c && data && ndata > 0, "mi355_cl_load: bad argument");
+  mh_invalidate(c);
   MI355_HIP(hipSetDevice(c->device));
   auto prob = std::make_unique<ClProblem>();
   for (int i = 0; i < ndata; ++i) {
@@ -343,6 +344,7 @@ int mi355_cl_set_binning(mi355_ctx* c, int32_t nCl, const int32_t* nbins, const 
   MI355_REQUIRE(nCl >= 1 && nCl <= 3, "Error in shapes of bins, shapefun, giving nCl=%d "
                 "[binnedClModel.py:163-164]", nCl);
   MI355_REQUIRE(lmax >= 1, "mi355_cl_set_binning: lmax=%d", lmax);
+  mh_invalidate(c);                                     // the parameter vector changes with the bins
   MI355_HIP(hipSetDevice(c->device));
   ClProblem* p = c->cl;
   p->binned = false;

@@ -140,6 +140,12 @@ namespace mi355 {
 // step-wise sampler hooks (gmh_api.hip) used by the shared mi355_mh_* entry points
 bool gmh_active(const mi355_ctx* c);
 void gmh_deactivate(mi355_ctx* c);
+// Loading data frees what a running sampler (and its captured graph) points at: every load
+// entry point ends the current sampler; the caller initialises a new one.
+inline void mh_invalidate(mi355_ctx* c) {
+  c->mh_ready = false;
+  gmh_deactivate(c);
+}
 int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, const double* inj_u);
 int gmh_adapt(mi355_ctx* c, double fac, int random_restart, int no_correlations, int rotate,
               int do_block);

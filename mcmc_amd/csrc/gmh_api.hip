@@ -39,7 +39,10 @@ constexpr int64_t kGraphMinSteps = 32;
 void gmh_destroy(GmhState* g) { delete g; }
 bool gmh_active(const mi355_ctx* c) { return c && c->gmh && c->gmh->active; }
 void gmh_deactivate(mi355_ctx* c) {
-  if (c->gmh) c->gmh->active = false;
+  if (c->gmh) {
+    c->gmh->active = false;
+    c->gmh->version += 1;          // a captured graph holds pointers of the old problem
+  }
 }
 
 static inline unsigned grid_for(int64_t n) { return static_cast<unsigned>(ceil_div64(n, 256)); }

@@ -271,3 +271,24 @@ def test_graph_replay_equals_direct_launches(kind):
             res.append(eng.mh_moments())
     for key in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
         assert np.array_equal(res[0][key], res[1][key]), key
+
+
+def test_loading_data_ends_the_running_sampler():
+    """A load frees what the sampler (and its captured graph) points at: the next mh_run must
+    fail cleanly instead of replaying a stale graph."""
+    from mcmc_amd import Engine
+    from mcmc_amd._lib import Mi355Error
+    from oracle import refcl as RC
+    model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.0, beam=0.0, lmax=600)
+    with Engine(seed=3) as eng:
+        eng.cl_load([d])
+        eng.cl_set_binning(model.bins, model.shapefun)
+        eng.mh_init_problem("cl", 32, truth, np.full(model.nparam, 0.02), randomize_start=False)
+        eng.mh_run(64)                                  # long enough for the graph path
+        eng.cl_load([d])
+        eng.cl_set_binning(model.bins, model.shapefun)
+        with pytest.raises(Mi355Error, match="not initialised"):
+            eng.mh_run(64)
+        eng.mh_init_problem("cl", 32, truth, np.full(model.nparam, 0.02), randomize_start=False)
+        eng.mh_run(64)
+        assert np.all(np.isfinite(eng.mh_moments()["lnPr"]))
