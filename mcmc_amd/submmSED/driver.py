@@ -96,10 +96,24 @@ def _pooled_stats(mom, samples, lnPr, params, burn_rows):
 
 def fit_catalogue(datasets, mod, like_cls=None, start=None, sigmas=None, nMC=nMC, nchains=64,
                   fac=None, random=True, randomrestart=False, seed=0x5EDC0FFEE, max_rows=128,
-                  burn=0.2, device=0, return_engine=False):
+                  burn=0.2, device=0, return_engine=False, batch_sources=8192):
     """All objects of `datasets` x `nchains` chains through the stages nMC on one GPU; returns the
     per-object records described in the module docstring plus, as a second value, a dict of
-    per-object diagnostics (Rhat [S,P], ESS [S,P], acceptance)."""
+    per-object diagnostics (Rhat [S,P], ESS [S,P], acceptance).  Catalogues larger than
+    `batch_sources` objects are fitted in consecutive batches: the thinned trace the statistics are
+    taken from comes back to the host (max_rows x nchains x P doubles per object)."""
+    if len(datasets) > batch_sources and not return_engine:
+        records, parts = [], []
+        for lo in range(0, len(datasets), batch_sources):
+            r, dg = fit_catalogue(datasets[lo:lo + batch_sources], mod, like_cls, start, sigmas, nMC,
+                                  nchains, fac, random, randomrestart, seed + lo, max_rows, burn, device,
+                                  False, batch_sources)
+            records += r
+            parts.append(dg)
+        diag = {k: np.concatenate([p[k] for p in parts]) for k in ("rhat", "ess", "accept_rate")}
+        diag["thin"] = parts[0]["thin"]
+        diag["resampled"] = [x for p in parts for x in p["resampled"]]
+        return records, diag
     if like_cls is None:
         like_cls = likelihood.SEDLikelihood_normalized
     start = np.asarray(mod.startfrom(random=random) if start is None else start, np.float64)

@@ -69,3 +69,14 @@ def test_stage_is_repeated_while_chains_have_not_moved():
     recs2, diag2 = drv.fit_catalogue(ds, M.submmModel1_normalized, start=(1., 2., 10.),
                                      sigmas=(2., 4., 4.), nMC=(300, 600), nchains=16, seed=3)
     assert diag2["resampled"] == []
+
+
+def test_large_catalogues_are_fitted_in_batches():
+    from mcmc_amd.submmSED import data as D, driver as drv, model as M
+    ds = D.readfluxes_DLC_2014(os.path.join(CAT, "herus_phot.csv"), UL25=False, getArp220=False)[:10]
+    kw = dict(start=(1., 2., 10.), sigmas=(2., 4., 4.), nMC=(200, 400), nchains=8, seed=5)
+    recs, diag = drv.fit_catalogue(ds, M.submmModel1_normalized, batch_sources=4, **kw)
+    assert len(recs) == 10 and diag["rhat"].shape == (10, 3) and diag["accept_rate"].shape == (10, 8)
+    assert [r[2] for r in recs] == [d.name + "(z=%5.3f)" % d.z for d in ds]
+    first, _ = drv.fit_catalogue(ds[:4], M.submmModel1_normalized, **kw)      # same seed as batch 0
+    np.testing.assert_array_equal(first[2][0][0], recs[2][0][0])
