@@ -99,6 +99,55 @@ def test_gaussian_data_quadforms():
         GaussianData(d, sig[:7])
 
 
+def test_generic_likelihood_marginalises_the_amplitude():
+    """The base Likelihood with a user model class and two GaussianData sets: lnLike, chi2,
+    lnNorm, lnLikeFull, lnPost follow Likelihood.py:78-163's formulae (numpy restatement)."""
+    from mcmc_amd.GaussianData import GaussianData
+    from mcmc_amd.Likelihood import Likelihood, ZeroPosterior
+    rng = np.random.default_rng(4)
+    sets = []
+    for n in (700, 1300):
+        x = np.linspace(-2, 2, n)
+        sig = rng.uniform(0.1, 0.3, n)
+        g = GaussianData(3.0 * np.exp(-0.5 * (x - 0.2) ** 2 / 0.49) + sig * rng.normal(size=n), sig)
+        g.x = x
+        sets.append(g)
+
+    class Bump(object):
+        def __init__(self, mu, width):
+            self.mu, self.width = mu, width
+
+        def __call__(self, dataset):
+            return np.exp(-0.5 * (dataset.x - self.mu) ** 2 / self.width ** 2) * (self.width > 0)
+
+        @staticmethod
+        def lnPrior(params):
+            return -0.5 * params[0] ** 2
+
+    like = Likelihood(data=sets[0], model=Bump)
+    like.adddata(sets[1])
+    assert len(like.data) == 2
+    p = (0.25, 0.65)
+    want = want_chi2 = want_norm = 0.0
+    for g in sets:
+        F = Bump(*p)(g)
+        ff, fd = np.dot(F / g.sig2, F), np.dot(F / g.sig2, g.d)
+        want += 0.5 * (fd * fd / ff - np.log(ff))
+        want_chi2 += np.dot((g.d - F) / g.sig2, g.d - F)
+        want_norm += -0.5 * ((g.n - 1) * np.log(2 * np.pi) + np.log(g.sig2).sum() +
+                             np.dot(g.d / g.sig2, g.d))
+        amp = fd / ff
+    assert like(p) == pytest.approx(want, rel=1e-12)
+    assert like.MLamplitude == pytest.approx(amp, rel=1e-12)          # of the last dataset
+    assert like.chi2(p) == pytest.approx(want_chi2, rel=1e-12)
+    assert like.lnNorm() == pytest.approx(want_norm, rel=1e-12)
+    assert like.lnLikeFull(p) == pytest.approx(want + want_norm, rel=1e-12)
+    assert like.lnPost(p) == pytest.approx(want - 0.5 * p[0] ** 2, rel=1e-12)
+    assert like.lnPostFull(p) == pytest.approx(want - 0.5 * p[0] ** 2 + want_norm, rel=1e-12)
+    with pytest.raises(ZeroPosterior):
+        like((0.25, -1.0))                                           # model vanishes: F^T N^-1 F = 0
+
+
 def test_sampler_arp220_matches_reference(arp220, g4):
     """Config C1: MCMC.sampler() - the reference's staged driver - on Arp220 with the reference's
     own draws injected: same stages, same accept counts, same adapted proposal widths, same
