@@ -22,7 +22,8 @@ import zlib
 import numpy as np
 
 REF = os.environ.get("MCMC_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("MCMC_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                        "..", "tests", "golden")
 
 
 def load_reference():
