@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--adapt", type=int, default=400, help="untimed stage-0 steps before newMCMC")
     ap.add_argument("--ess-steps", type=int, default=2000,
                     help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
+    ap.add_argument("--incremental-steps", type=int, default=3,
+                    help="extra launches with the opt-in incremental sampler (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -161,6 +163,29 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Opt-in incremental evaluation (mi355_mh_set_incremental): the same chains, a step evaluates
+    # only what its parameter touches.  Reported beside the headline figure, never as `value`
+    # (which stays the full evaluation of every proposed point).
+    inc_out = {}
+    if args.incremental_steps > 0:
+        eng.mh_set_incremental(True)
+        if eng.mh_incremental_active:
+            eng.mh_run(inner)
+            barrier()
+            t2 = time.perf_counter()
+            inc_ms = []
+            for _ in range(args.incremental_steps):
+                one_step()
+                inc_ms.append(eng.last_kernel_ms)
+            barrier()
+            t_inc = time.perf_counter() - t2
+            inc_out = {"incremental_sampler": {
+                "value": float(S) * C * inner * args.incremental_steps / t_inc, "unit": "MH steps/s per GPU",
+                "kernel": "k_mh_run_inc<M2N>", "kernel_ms": float(np.mean(inc_ms)),
+                "note": "opt-in: same chains as the full evaluation (tests/test_sed_gpu.py), the unit "
+                        "band terms of the unchanged component kept across single-parameter steps"}}
+        eng.mh_set_incremental(False)
+
     # ESS/s (second half of BASELINE.json's metric): a separately timed run that keeps a thinned
     # trace (100 rows per chain) in HBM, then the multi-chain BDA3 estimator on the device; per
     # source the minimum over parameters, summed over sources and (chains being independent) ranks
@@ -223,6 +248,7 @@ def main():
         "rhat_median": float(torch.nanmedian(rhat).item()),
     }
     out.update(ess_out)
+    out.update(inc_out)
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:

@@ -134,6 +134,21 @@ int mi355_mh_init(mi355_ctx* ctx, int32_t C, const double* theta0, int32_t theta
 int mi355_mh_run(mi355_ctx* ctx, int64_t nsteps, int32_t thin, const double* inj_normals,
                  const double* inj_uniforms);
 
+/* Incremental evaluation for mi355_mh_run (off by default).  The reference rebuilds
+ * model(*params)(data) from scratch at every step (Likelihood.py:70-75 -> model.py:394-396); with
+ * one parameter per block (doBlock, MCMC.py:230-234) a step of a two-component normalised model
+ * changes one of (A, beta, T) of one component, and the other component's band fluxes - and for
+ * an amplitude step every band flux - are those of the current state.  With on=1 the fused SED
+ * sampler keeps them in registers and evaluates only what the moved parameter touches; lnLike of
+ * the proposed point is the same function of theta' (rounding differs in the last bits), the
+ * draws are the same, so the chain is the one the full evaluation produces (held to the same
+ * 1e-12 against the reference's traces).  Applies when: submmModel2_normalized[_logA], the
+ * catalogue passed the fast-path check of mi355_sed_load, no source has more than 8 bands, mi355_mh_init was given
+ * param_blocks = 0..P-1; otherwise mi355_mh_run evaluates in full as before.
+ * mi355_mh_incremental_active: 1 if the next mi355_mh_run of this context would use it. */
+int mi355_mh_set_incremental(mi355_ctx* ctx, int32_t on);
+int mi355_mh_incremental_active(mi355_ctx* ctx);
+
 /* mean(burn=1), stdev(burn=1)**2 (ddof=0, MCMC.py:290-307) over the steps run since the last
  * init/adapt, naccept (MCMC.py:179,269), per-block accept counts (:181,271) and the current
  * lnPr / position.  Host outputs, all nullable: mean,var,theta [S,C,P]; naccept,lnPr [S,C];

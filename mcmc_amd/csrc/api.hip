@@ -112,6 +112,19 @@ struct LaunchStart {
   }
 };
 
+// Whether the fused SED sampler of this context runs as k_mh_run_inc: asked for, a two-component
+// normalised model on the clamp-free path, bands within the register cache, one parameter per
+// block with block b = parameter b.
+static bool incremental_applies(const mi355_ctx* c) {
+  if (!c->incremental || !c->mh_ready || gmh_active(c)) return false;
+  const int m = c->model.model;
+  if (m != MI355_SED_M2N && m != MI355_SED_M2N_LOGA) return false;
+  if (c->kc.fast_ok == 0.0 || c->nb_most > kIncBands || c->nblock != c->mhP || c->npn != 1) return false;
+  for (int b = 0; b < c->nblock; ++b)
+    if (c->blockmask[b] != (1u << b)) return false;
+  return true;
+}
+
 template <int M>
 struct LaunchRun {
   static int run(mi355_ctx* c, const MhArgs& a) {
@@ -120,6 +133,16 @@ struct LaunchRun {
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
+    if constexpr (M == MI355_SED_M2N || M == MI355_SED_M2N_LOGA) {
+      const size_t lds_inc = lds + 2 * static_cast<size_t>(kIncBands) * bs * sizeof(double);
+      if (incremental_applies(c) && lds_inc <= kLdsLimit) {
+        hipLaunchKernelGGL(k_mh_run_inc<M>, dim3(grid), dim3(bs), lds_inc, c->stream, a);
+        MI355_HIP(hipGetLastError());
+        if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+        if (!c->capturing) c->ev_valid = true;
+        return 0;
+      }
+    }
     if (c->kc.fast_ok != 0.0)
       hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
     else
@@ -289,6 +312,8 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
   c->P = m->nparam;
   c->S = S;
   c->nbm = nb_max;
+  c->nb_most = 0;
+  for (int64_t s = 0; s < S; ++s) c->nb_most = std::max<int>(c->nb_most, nb[s]);
   auto dd_log = [](double v, double* hi, double* lo) {   // log2(v) as hi + lo (x87 80-bit log2l)
     const long double l = log2l(static_cast<long double>(v));
     *hi = static_cast<double>(l);
@@ -568,6 +593,14 @@ int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n
   MI355_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
+
+int mi355_mh_set_incremental(mi355_ctx* c, int32_t on) {
+  MI355_REQUIRE(c, "null context");
+  c->incremental = on != 0;
+  return 0;
+}
+
+int mi355_mh_incremental_active(mi355_ctx* c) { return (c && incremental_applies(c)) ? 1 : 0; }
 
 int64_t mi355_mh_stream_pos(mi355_ctx* c, int32_t which) {
   if (!c) return -1;

@@ -101,6 +101,7 @@ struct mi355_ctx {
   int P = 0;
   int64_t S = 0;
   int nbm = 0;
+  int nb_most = 0;                // largest nb[s] of the catalogue (<= nbm, the row width)
   mi355::DevBuf<double> bands;   // [S][kBandFields][nbm]
   mi355::DevBuf<int32_t> nb;     // [S]
 
@@ -114,6 +115,7 @@ struct mi355_ctx {
   uint32_t blockmask[mi355::kMaxParam] = {0};
   int32_t rank_in_block[mi355::kMaxParam] = {0};
   int npn = 1;                    // normals drawn per step in free-running mode
+  bool incremental = false;       // mi355_mh_set_incremental: k_mh_run_inc where it applies
   int64_t step_total = 0;         // Philox stream position (never reset)
   int64_t stage_step = 0;         // steps since the last init/adapt (iBlock = stage_step % nblock)
   int64_t stage = 0;              // number of init/adapt calls (keys the start stream)

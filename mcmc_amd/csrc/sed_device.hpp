@@ -177,6 +177,55 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
   }
 }
 
+// ---- pieces of the incremental sampler (k_mh_run_inc) ------------------------------------------
+// The normalised greybody of ONE component at every band of the source, without its amplitude:
+//   u[j] = (nu_j/nu_b)^(3+beta) expm1(h nu_b/kT) / expm1(h nu_j/kT)            model.py:107-109
+// in the base-2 form of sed_lnlike_fast (same kernels, same domain: fast_ok).  Bands are handled
+// in pairs under one wave-uniform branch (the lanes of a wave share the source), so that four
+// exponent chains are in flight; u[j] = 0 for j >= nb.
+constexpr int kIncBands = 8;            // bands per source the register cache is sized for
+
+__device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands& B,
+                                               const SedConsts& k, double* u) {
+  const double rT = rcp_nr2(T);
+  const double em = exp2m1_fast(k.hk_nub2 * rT);
+#pragma unroll
+  for (int q = 0; q < kIncBands; q += 2) {
+    if (q < B.nb) {
+      const int j1 = (q + 1 < B.nb) ? q + 1 : q;           // odd nb: the last band twice
+      const double ya = B.hnu2(q) * rT, yb = B.hnu2(j1) * rT;
+      const double na = exp2_fast(fma(e3, B.lhi(q), -ya), 0.0) * em;
+      const double nb_ = exp2_fast(fma(e3, B.lhi(j1), -yb), 0.0) * em;
+      const double da = 1.0 - exp2_fast(-ya, 0.0), db = 1.0 - exp2_fast(-yb, 0.0);
+      u[q] = div_fast(na, da);
+      const double ub = div_fast(nb_, db);
+      u[q + 1] = (q + 1 < B.nb) ? ub : 0.0;
+    } else {
+      u[q] = 0.0;
+      u[q + 1] = 0.0;
+    }
+  }
+}
+
+// chi2 of the two-component model A_x u_x + A_o u_o against the source's photometry
+// (GaussianData.py:47,64); terms beyond nb have u = 0 and get weight 0.
+__device__ __forceinline__ double sed_chi2_two(const Bands& B, double Ax, const double* ux,
+                                               double Ao, const double* uo) {
+  double chi2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < kIncBands; q += 2) {
+    if (q < B.nb) {
+      const bool two = q + 1 < B.nb;
+      const int j1 = two ? q + 1 : q;
+      const double ra = B.d(q) - fma(Ax, ux[q], Ao * uo[q]);
+      const double rb = B.d(j1) - fma(Ax, ux[q + 1], Ao * uo[q + 1]);
+      chi2 = fma(ra * B.w(q), ra, chi2);
+      chi2 = fma(rb * (two ? B.w(j1) : 0.0), rb, chi2);
+    }
+  }
+  return chi2;
+}
+
 // ---- likelihood, exact path --------------------------------------------------------------------
 // Returns like.lnLike(theta) WITHOUT the prior for ANY theta, with the reference's IEEE edge
 // behaviour (overflow -> inf -> 0 flux, NaN propagation).  derived[0..1] receive the ML amplitudes

@@ -381,6 +381,181 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   a.naccept[n] = nacc;
 }
 
+// ---- incremental variant of k_mh_run for the two-component normalised models --------------------
+// In single-parameter block mode (the production configuration: doBlock with one parameter per
+// block, driver.py:329-332, MCMC.py:230-234) a step moves ONE of (A1, beta1, T1, A2, beta2, T2).
+// The band fluxes of a component depend on its own (beta, T) only and enter the model linearly
+// through A, so a chain keeps the unit band terms u_c[j] of both components of its CURRENT state
+// and a step evaluates only what its parameter touches:
+//   A_c         : nothing but the chi2 sum (no transcendental at all),
+//   beta_c, T_c : the unit terms of component c (2 nb exponentials instead of 4 nb),
+// then chi2 = sum_j w_j (d_j - A_1 u_1j - A_2 u_2j)^2 as always.  The value returned for the
+// proposed point is the same lnLike(theta') as a full evaluation up to rounding (the terms are
+// the same functions of theta'; only the association of the products differs), so the chain is
+// the one k_mh_run produces - tests/test_sed_gpu.py holds it to the same 1e-12 against the oracle
+// and the reference's traces.
+// The cache lives in LDS, [2 slots][kIncBands][blockDim] doubles in front of the band tables
+// (lane-consecutive, conflict-free); a per-lane bit says which slot holds component 0, so that
+// package()'s exchange of the components costs one XOR.  The block index is launch-uniform, so
+// which parameter moves is a scalar branch.  Requirements (checked by the host, which otherwise
+// launches k_mh_run): fast_ok, every nb[s] <= kIncBands, nblock == P with block b = parameter b.
+// No counterpart in the reference, which rebuilds model(*params)(data) at every step
+// (Likelihood.py:70-75); opt-in through mi355_mh_set_incremental.
+template <int MODEL>
+__global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
+  static_assert(MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA, "two-component models");
+  constexpr int P = 6;
+  constexpr bool LG = MODEL == MI355_SED_M2N_LOGA;
+  extern __shared__ double smem[];
+  const int slot = kIncBands * blockDim.x;                 // doubles per cache slot
+  double* tables = smem + 2 * slot;
+  const int stride = kBandFields * a.nbm;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
+  const int64_t s_first = n0 / a.C;
+  const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  stage_bands(tables, a.bands, s_first, nsrc, stride);
+  const int64_t n = n0 + threadIdx.x;
+  if (n >= a.N) return;
+  const int64_t s = n / a.C;
+  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s]};
+
+  double th[P], mu[P], m2[P];
+  uint32_t accb[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    th[i] = a.theta[i * a.N + n];
+    mu[i] = a.mean[i * a.N + n];
+    m2[i] = a.m2[i * a.N + n];
+    accb[i] = a.accept[i * a.N + n];
+  }
+  double lnPr = a.lnPr[n];
+  uint32_t nacc = a.naccept[n];
+
+  // the cache of the current state (rebuilt at every launch entry): amplitudes in registers,
+  // unit terms in this lane's column of the two LDS slots
+  double Ac[2] = {LG ? exp10_fast(th[0]) : th[0], LG ? exp10_fast(th[3]) : th[3]};
+  double* mine = smem + threadIdx.x;
+  int flip = 0;                                            // slot of component 0
+  {
+    double un[kIncBands];
+    sed_unit_terms(3.0 + th[1], th[2], B, a.k, un);
+#pragma unroll
+    for (int j = 0; j < kIncBands; ++j) mine[j * blockDim.x] = un[j];
+    sed_unit_terms(3.0 + th[4], th[5], B, a.k, un);
+#pragma unroll
+    for (int j = 0; j < kIncBands; ++j) mine[slot + j * blockDim.x] = un[j];
+  }
+
+  const bool inject = a.inj_n != nullptr;
+  int blk = static_cast<int>(a.stage_step % P);
+  int thin_ctr = 0;
+  int64_t row = 0;
+  double za = 0.0, zb = 0.0, ua = 0.0, ub = 0.0;
+
+  for (int64_t t = 0; t < a.nsteps; ++t) {
+    const uint64_t step = static_cast<uint64_t>(a.step_total + t);
+    const int comp = blk >= 3 ? 1 : 0, kind = blk - 3 * comp;   // 0 amplitude, 1 beta, 2 T
+    double z, u;
+    if (inject) {
+      z = a.inj_n[(t * a.N + n) * P + blk];                  // Proposal.py:151,156-159
+      u = a.inj_u[t * a.N + n];
+    } else {
+      if (t == 0 || (step & 1u) == 0) {
+        philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+        philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
+      }
+      z = (step & 1u) ? zb : za;
+      u = (step & 1u) ? ub : ua;
+    }
+    const double moved = a.sigma[blk * a.N + n] * z;       // the one width this step needs
+    double nw[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) nw[i] = (i == blk) ? th[i] + moved : th[i];
+    // the moved component as proposed, before package() may exchange the two
+    const double pa = comp ? nw[3] : nw[0], pb = comp ? nw[4] : nw[1], pT = comp ? nw[5] : nw[2];
+    const bool swapped = nw[2] > nw[5];
+    sed_package<MODEL>(nw);                                // Proposal.py:164
+    const double prior = sed_prior<MODEL>(nw, a.k);
+    bool accepted = false;
+    double next = lnPr;
+    double un[kIncBands];
+    double An = comp ? Ac[1] : Ac[0];
+    const double Ao = comp ? Ac[0] : Ac[1];
+    double* ux = mine + ((comp ^ flip) ? slot : 0);        // cached terms of the moved component
+    const double* uo = mine + ((comp ^ flip) ? 0 : slot);  // ... and of the other one
+    if (prior > 0.0) {
+      if (kind == 0) {
+        An = LG ? exp10_fast(pa) : pa;
+#pragma unroll
+        for (int j = 0; j < kIncBands; ++j) un[j] = ux[j * blockDim.x];
+      } else {
+        sed_unit_terms(3.0 + pb, pT, B, a.k, un);
+      }
+      double uot[kIncBands];
+#pragma unroll
+      for (int j = 0; j < kIncBands; ++j) uot[j] = uo[j * blockDim.x];
+      const double v = -0.5 * sed_chi2_two(B, An, un, Ao, uot);
+      const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
+      if (!bad) {
+        const double lnalpha = v - lnPr;                   // :251
+        const bool reject = !(lnalpha >= 0.0) && !(exp_fast(lnalpha) > u);   // :264
+        if (!reject) {
+          accepted = true;
+          next = v;
+        }
+      }
+    }
+    if (accepted) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) th[i] = nw[i];
+      lnPr = next;
+      ++nacc;                                              // :269
+#pragma unroll
+      for (int b = 0; b < P; ++b) accb[b] += (b == blk) ? 1u : 0u;   // :271
+      if (kind == 0) {
+        if (comp) Ac[1] = An; else Ac[0] = An;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kIncBands; ++j) ux[j * blockDim.x] = un[j];
+      }
+      if (swapped) {                                       // the cache follows package()
+        const double ta = Ac[0]; Ac[0] = Ac[1]; Ac[1] = ta;
+        flip ^= 1;
+      }
+    }
+    blk = (blk + 1 == P) ? 0 : blk + 1;                    // :278-279
+
+    const double rn = rcp_nr(static_cast<double>(a.nsamp0 + t + 1));
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const double dlt = th[i] - mu[i];
+      mu[i] += dlt * rn;
+      m2[i] += dlt * (th[i] - mu[i]);
+    }
+    if (a.thin > 0) {
+      if (++thin_ctr == a.thin) {
+        thin_ctr = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) a.tr_theta[(row * P + i) * a.N + n] = th[i];
+        a.tr_lnPr[row * a.N + n] = lnPr;
+        a.tr_acc[row * a.N + n] = accepted ? 1 : 0;
+        ++row;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    a.theta[i * a.N + n] = th[i];
+    a.mean[i * a.N + n] = mu[i];
+    a.m2[i * a.N + n] = m2[i];
+    a.accept[i * a.N + n] = accb[i];
+  }
+  a.lnPr[n] = lnPr;
+  a.naccept[n] = nacc;
+}
+
 // ---- RNG diagnostic -----------------------------------------------------------------------
 __global__ void k_rng_dump(uint64_t seed, int64_t step0, int64_t nsteps, int64_t N, int npn,
                            double* normals, double* uniforms) {

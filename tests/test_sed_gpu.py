@@ -125,6 +125,22 @@ def test_injected_chain_matches_reference_trace(eng, g2, g3, name):
     """G3: with the reference's own proposal draws injected, the device chain reproduces the
     reference trace step for step (accept pattern identical, samples/lnPr to rounding), its
     naccept / per-block counts, and mean/stdev with burn=1."""
+    _check_g3_chain(eng, g2, g3, name, incremental=False)
+
+
+@pytest.mark.parametrize("name", ["m2n_block", "m2n_fixedbeta"])
+def test_incremental_injected_chain_matches_reference_trace(eng, g2, g3, name):
+    """The same G3 traces of the reference through the incremental sampler (k_mh_run_inc,
+    mi355_mh_set_incremental): two-component model, one parameter per block, one with sigma = 0
+    blocks."""
+    eng.mh_set_incremental(True)
+    try:
+        _check_g3_chain(eng, g2, g3, name, incremental=True)
+    finally:
+        eng.mh_set_incremental(False)
+
+
+def _check_g3_chain(eng, g2, g3, name, incremental):
     mid, _ = _g3_setup(eng, g2, g3, name)
     P = R.MODEL_NPARAM[mid]
     do_block = bool(g3[name + "__do_block"])
@@ -137,6 +153,7 @@ def test_injected_chain_matches_reference_trace(eng, g2, g3, name):
                 param_blocks=np.arange(P) if do_block else None, randomize_start=False)
     m0 = eng.mh_moments()
     assert abs(m0["lnPr"][0, 0] - lnPr[0]) <= 1e-12 * abs(lnPr[0])
+    assert eng.mh_incremental_active == incremental
     eng.mh_run(nsteps, thin=1, inj_normals=normals, inj_uniforms=uniforms)
     tr_s, tr_l, tr_a = eng.mh_trace()
     np.testing.assert_array_equal(tr_a[:, 0, 0], acc[1:])
@@ -229,6 +246,77 @@ def test_free_running_chains_match_oracle(eng, mid, do_block):
             np.testing.assert_allclose(tr_s[:, s, c], os_[1:], rtol=1e-12)
             np.testing.assert_allclose(tr_l[:, s, c], ol[1:], rtol=1e-12)
             assert mom["naccept"][s, c] == ch.naccept
+
+
+@pytest.mark.parametrize("mid", [R.M2N, R.M2N_LOGA])
+def test_incremental_sampler_equals_full_evaluation(eng, mid):
+    """k_mh_run_inc against k_mh_run on the same Philox draws: 37 ragged sources (0 to 8 bands,
+    odd counts included) x 70 chains, three launches whose step counts leave the block counter
+    and the draw-pair parity at every offset, wide steps so that chains swap their components
+    (package()) many times.  Accept decisions identical, positions / lnPr / moments to 1e-12;
+    both are held to the oracle by the tests above."""
+    S, C = 37, 70
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=77)
+    nb = (np.arange(S) % 9).astype(np.int32)
+    nb[-3:] = 8
+    eng.sed_load(mid, nb, nu, d, sig)
+    if mid == R.M2N:
+        start, sigma = np.array([1, 2, 10, 0.1, 2, 20.]), np.array([0.3, 0.4, 6.0, 0.2, 0.4, 8.0])
+    else:
+        start, sigma = np.array([0.0, 2, 10, -1.0, 2, 20.]), np.array([0.2, 0.4, 6.0, 0.3, 0.4, 8.0])
+    launches = (301, 64, 235)
+    out = {}
+    for inc in (False, True):
+        eng.set_stream_pos(1000, 3)
+        eng.mh_set_incremental(inc)
+        try:
+            eng.mh_init(C, start, sigma, param_blocks=np.arange(6), randomize_start=True)
+            assert eng.mh_incremental_active == inc
+            traces = []
+            for n in launches:
+                eng.mh_run(n, thin=1)
+                traces.append([x.copy() for x in eng.mh_trace()])
+            out[inc] = (traces, eng.mh_moments(), eng.rhat())
+        finally:
+            eng.mh_set_incremental(False)
+    swaps = 0
+    for (fs, fl, fa), (is_, il, ia) in zip(out[False][0], out[True][0]):
+        np.testing.assert_array_equal(ia, fa)
+        np.testing.assert_allclose(is_, fs, rtol=1e-12, atol=0)
+        # sources with 1 to 6 bands are fitted exactly by some points (chi2 -> 0, the residuals
+        # cancel): there the 1e-12 is relative to the terms of the sum, hence the absolute floor
+        np.testing.assert_allclose(il, fl, rtol=RTOL_LNL, atol=1e-15)
+        swaps += int(np.sum((np.diff(fs[..., 0], axis=0) != 0) & (np.diff(fs[..., 3], axis=0) != 0)))
+    assert swaps > 100, "the case is meant to exercise package() swaps"
+    mf, mi = out[False][1], out[True][1]
+    np.testing.assert_array_equal(mi["naccept"], mf["naccept"])
+    np.testing.assert_array_equal(mi["accept"], mf["accept"])
+    np.testing.assert_allclose(mi["mean"], mf["mean"], rtol=1e-11)
+    np.testing.assert_allclose(mi["var"], mf["var"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-9)
+
+
+def test_incremental_falls_back_where_it_does_not_apply(eng):
+    """Asked for but not applicable (all parameters in one block; a one-component model; more
+    than 8 bands): mi355_mh_run evaluates in full as before and says so."""
+    nu, d, sig, truth = R.synth_sed_catalogue(2, seed=5)
+    nb = np.array([8, 8], np.int32)
+    eng.mh_set_incremental(True)
+    try:
+        eng.sed_load(R.M2N, nb, nu, d, sig)
+        eng.mh_init(4, truth[:, None, :].repeat(4, 1), np.full(6, 0.01), param_blocks=None,
+                    randomize_start=False)
+        assert not eng.mh_incremental_active
+        eng.mh_init(4, truth[:, None, :].repeat(4, 1), np.full(6, 0.01), param_blocks=np.arange(6),
+                    randomize_start=False)
+        assert eng.mh_incremental_active
+        eng.sed_load(R.M1N, nb, nu, d, sig)
+        eng.mh_init(4, np.array([1.0, 2, 20]), np.full(3, 0.01), param_blocks=np.arange(3),
+                    randomize_start=False)
+        assert not eng.mh_incremental_active
+        eng.mh_run(10)
+    finally:
+        eng.mh_set_incremental(False)
 
 
 @pytest.mark.parametrize("C,nrows", [(64, 100), (40, 37), (100, 128), (256, 50), (2, 9)])
