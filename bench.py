@@ -254,7 +254,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -26,7 +26,10 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # MI355_DIST_FORCE=1: create the process group for a single rank too, so that a one-GPU box
+    # runs the collectives of the multi-rank path through RCCL itself
+    force = os.environ.get("MI355_DIST_FORCE", "") not in ("", "0")
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # MI355_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs
             # than ranks (gloo stages CUDA tensors through the host)
@@ -44,7 +47,7 @@ def _world(group=None):
 
 
 def allreduce_sum_(t, group=None):
-    if _world(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
