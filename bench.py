@@ -112,6 +112,12 @@ def main():
         nu0, d0, sig0, _ = _synth.sed_catalogue(args.sources)
         cpu = cpu_baseline(nu0, d0, sig0, args.cpu_seconds)
 
+    # stdout carries exactly one JSON line: libraries that write to file descriptor 1 (RCCL prints
+    # a version banner there when the first communicator is made) are sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from mcmc_amd import Engine, synth
     from mcmc_amd import distributed as D
@@ -252,7 +258,8 @@ def main():
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

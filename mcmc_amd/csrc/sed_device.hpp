@@ -143,7 +143,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     // two plain 2^z kernels and a subtraction instead of a power and an expm1 (1 - 2^-y loses
     // log2(1/x) bits, x >= 0.02 is part of fast_ok); the exponent a - y is one FMA on the high
     // part of log2(nu/nu_b) (its rounding, |a - y| 2^-53 in the result, is the error that
-    // matters; tools/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
+    // matters; tests/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
     // share one division, (n1 d2 + n2 d1) / (d1 d2) with d in (0, 1].
     const double ae1 = A1 * exp2m1_fast(k.hk_nub2 * rT1);
     const double ae2 = A2 * exp2m1_fast(k.hk_nub2 * rT2);
@@ -208,17 +208,19 @@ __device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands&
 }
 
 // chi2 of the two-component model A_x u_x + A_o u_o against the source's photometry
-// (GaussianData.py:47,64); terms beyond nb have u = 0 and get weight 0.
-__device__ __forceinline__ double sed_chi2_two(const Bands& B, double Ax, const double* ux,
-                                               double Ao, const double* uo) {
+// (GaussianData.py:47,64); terms beyond nb have u = 0 and get weight 0.  ux / uo are read with the
+// given element strides (1: a register array; blockDim.x: a lane's column of the LDS cache, which
+// keeps the cached terms out of the register budget).
+__device__ __forceinline__ double sed_chi2_two(const Bands& B, double Ax, const double* ux, int sx,
+                                               double Ao, const double* uo, int so) {
   double chi2 = 0.0;
 #pragma unroll
   for (int q = 0; q < kIncBands; q += 2) {
     if (q < B.nb) {
       const bool two = q + 1 < B.nb;
       const int j1 = two ? q + 1 : q;
-      const double ra = B.d(q) - fma(Ax, ux[q], Ao * uo[q]);
-      const double rb = B.d(j1) - fma(Ax, ux[q + 1], Ao * uo[q + 1]);
+      const double ra = B.d(q) - fma(Ax, ux[q * sx], Ao * uo[q * so]);
+      const double rb = B.d(j1) - fma(Ax, ux[(q + 1) * sx], Ao * uo[(q + 1) * so]);
       chi2 = fma(ra * B.w(q), ra, chi2);
       chi2 = fma(rb * (two ? B.w(j1) : 0.0), rb, chi2);
     }

@@ -485,17 +485,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
     double* ux = mine + ((comp ^ flip) ? slot : 0);        // cached terms of the moved component
     const double* uo = mine + ((comp ^ flip) ? 0 : slot);  // ... and of the other one
     if (prior > 0.0) {
-      if (kind == 0) {
+      const int bd = static_cast<int>(blockDim.x);
+      double v;
+      if (kind == 0) {                                     // amplitude step: no transcendental
         An = LG ? exp10_fast(pa) : pa;
-#pragma unroll
-        for (int j = 0; j < kIncBands; ++j) un[j] = ux[j * blockDim.x];
+        v = -0.5 * sed_chi2_two(B, An, ux, bd, Ao, uo, bd);
       } else {
         sed_unit_terms(3.0 + pb, pT, B, a.k, un);
+        v = -0.5 * sed_chi2_two(B, An, un, 1, Ao, uo, bd);
       }
-      double uot[kIncBands];
-#pragma unroll
-      for (int j = 0; j < kIncBands; ++j) uot[j] = uo[j * blockDim.x];
-      const double v = -0.5 * sed_chi2_two(B, An, un, Ao, uot);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         const double lnalpha = v - lnPr;                   // :251

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the Cl (config C4) and beam (config C5) likelihood kernels on one MI355X.
-    python tools/bench_clbeam.py cl [nb npar calib beam chains]
-    python tools/bench_clbeam.py beam [maps npix_side chains]
+    python tests/bench_clbeam.py cl [nb npar calib beam chains]
+    python tests/bench_clbeam.py beam [maps npix_side chains]
 Prints one JSON line per workload (kernel time from HIP events on the library's stream)."""
 import json
 import os
