@@ -334,17 +334,18 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
       const bool live = j < nb[s];
       const double v = live ? nu[s * nb_max + j] : m->nu_b;
       const double sg = live ? sig[s * nb_max + j] : 1.0;
-      o[0 * nb_max + j] = v;
-      o[1 * nb_max + j] = m->h_over_k * v;       // x = h_over_k*nu/T     model.py:103
-      o[2 * nb_max + j] = v / m->nu_b;           // nu/nu_norm            model.py:109
-      o[3 * nb_max + j] = live ? d[s * nb_max + j] : 0.0;
-      o[4 * nb_max + j] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
+      o[j * kBandFields + kF_NU] = v;
+      o[j * kBandFields + kF_HNU] = m->h_over_k * v;       // x = h_over_k*nu/T     model.py:103
+      o[j * kBandFields + kF_RATIO] = v / m->nu_b;           // nu/nu_norm            model.py:109
+      o[j * kBandFields + kF_D] = live ? d[s * nb_max + j] : 0.0;
+      o[j * kBandFields + kF_W] = live ? 1.0 / (sg * sg) : 0.0;   // 1/sig2   GaussianData.py:19,47
       // log2 of the band's power-law base (the rounded double the reference raises to 3+beta)
-      dd_log(base_is_nu ? v : v / m->nu_b, &o[5 * nb_max + j], &o[6 * nb_max + j]);
-      o[7 * nb_max + j] = static_cast<double>(static_cast<long double>(o[1 * nb_max + j]) *
+      dd_log(base_is_nu ? v : v / m->nu_b, &o[j * kBandFields + kF_LHI],
+             &o[j * kBandFields + kF_LLO]);
+      o[j * kBandFields + kF_HNU2] = static_cast<double>(static_cast<long double>(o[j * kBandFields + kF_HNU]) *
                                               1.442695040888963407359924681001892137L);
       if (live)
-        MI355_REQUIRE(v > 0.0 && std::isfinite(v) && std::fabs(o[5 * nb_max + j]) < 100.0,
+        MI355_REQUIRE(v > 0.0 && std::isfinite(v) && std::fabs(o[j * kBandFields + kF_LHI]) < 100.0,
                       "source %lld band %d: frequency %g GHz out of range",
                       static_cast<long long>(s), j, v);
     }
@@ -360,8 +361,9 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     for (int64_t s = 0; s < S && ok; ++s)
       for (int j = 0; j < nb[s]; ++j) {
         const double* o = h.data() + s * stride;
-        if (!(o[1 * nb_max + j] / m->Tmin < 300.0) || !(emax * std::fabs(o[5 * nb_max + j]) < 300.0) ||
-            !(m->Tmax > 0.0 && o[1 * nb_max + j] / m->Tmax >= 0.02)) {   // 1 - 2^-y keeps >= 47 bits
+        if (!(o[j * kBandFields + kF_HNU] / m->Tmin < 300.0) ||
+            !(emax * std::fabs(o[j * kBandFields + kF_LHI]) < 300.0) ||
+            !(m->Tmax > 0.0 && o[j * kBandFields + kF_HNU] / m->Tmax >= 0.02)) {   // 1 - 2^-y keeps >= 47 bits
           ok = false;
           break;
         }

@@ -64,7 +64,20 @@ struct DevBuf {
 
 constexpr int kMaxParam = 8;     // largest nparam of any SED model is 6
 constexpr int kMaxDevices = 64;  // size of per-device caches of launch attributes
-constexpr int kBandFields = 8;   // nu, h/k*nu, nu/nu_b, d, 1/sig^2, log2(base) hi, lo, h/k*nu*log2(e)
+// Band table of a source: [nb_max][kBandFields], the fields of one band adjacent (one LDS address
+// per band, the rest are immediate offsets; (d, 1/sig^2) and (log2 base, h nu/k log2 e) are
+// 16-byte aligned pairs).
+constexpr int kBandFields = 8;
+enum BandField {
+  kF_NU = 0,     // nu
+  kF_HNU = 1,    // h/k * nu
+  kF_D = 2,      // flux
+  kF_W = 3,      // 1/sig^2
+  kF_LHI = 4,    // log2(base), high part
+  kF_HNU2 = 5,   // h/k * nu * log2(e)
+  kF_LLO = 6,    // log2(base), low part
+  kF_RATIO = 7   // nu / nu_b
+};
 constexpr int kBlockThreads = 256;
 
 struct ClProblem;     // cl_api.hip
@@ -102,7 +115,7 @@ struct mi355_ctx {
   int64_t S = 0;
   int nbm = 0;
   int nb_most = 0;                // largest nb[s] of the catalogue (<= nbm, the row width)
-  mi355::DevBuf<double> bands;   // [S][kBandFields][nbm]
+  mi355::DevBuf<double> bands;   // [S][nbm][kBandFields]
   mi355::DevBuf<int32_t> nb;     // [S]
 
   // --- chain state (N = S*C chains, parameter-major so lanes coalesce) --------------

@@ -125,6 +125,14 @@ __device__ __forceinline__ double exp2_fast(double y, double extra) {
   return ldexp(fma(exp2m1_over_f(f), f, 1.0), static_cast<int>(fn));
 }
 
+// 2^y, |y| < 1000 (bounded by the caller).  Not exp2_fast(y, 0.0): without fast-math the
+// compiler must keep the addition of a zero low part (it turns -0 into +0).
+__device__ __forceinline__ double exp2_fast(double y) {
+  const double fn = rint(y);
+  const double f = y - fn;                  // exact
+  return ldexp(fma(exp2m1_over_f(f), f, 1.0), static_cast<int>(fn));
+}
+
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.

@@ -11,23 +11,35 @@
 
 namespace mi355 {
 
-// band table of one source in LDS: [kBandFields][nbm]
+// band table of one source in LDS: [nbm][kBandFields] (common.hpp: BandField)
 struct Bands {
   const double* base;
   int nbm;
   int nb;
-  __device__ __forceinline__ double nu(int j) const { return base[0 * nbm + j]; }
-  __device__ __forceinline__ double hnu(int j) const { return base[1 * nbm + j]; }    // h/k * nu
-  __device__ __forceinline__ double ratio(int j) const { return base[2 * nbm + j]; }  // nu / nu_b
-  __device__ __forceinline__ double d(int j) const { return base[3 * nbm + j]; }
-  __device__ __forceinline__ double w(int j) const { return base[4 * nbm + j]; }      // 1/sig^2
+  // Loop bound of the fast path: nb, or a wave-uniform upper bound of it (wave_max_uniform) so
+  // that the band loop is scalar control flow.  Rows nb <= j < nbm of a table are padding with
+  // weight 0 and benign values (nu = nu_b, d = 0): they add exactly 0 to a chi-square.
+  int nbu;
+  __device__ __forceinline__ double f(int j, int field) const { return base[j * kBandFields + field]; }
+  __device__ __forceinline__ double nu(int j) const { return f(j, kF_NU); }
+  __device__ __forceinline__ double hnu(int j) const { return f(j, kF_HNU); }      // h/k * nu
+  __device__ __forceinline__ double ratio(int j) const { return f(j, kF_RATIO); }  // nu / nu_b
+  __device__ __forceinline__ double d(int j) const { return f(j, kF_D); }
+  __device__ __forceinline__ double w(int j) const { return f(j, kF_W); }          // 1/sig^2
   // log2(base) = lhi + llo of the band's power-law base: nu/nu_b for the normalised models,
   // nu for submmModel1/2 (set per catalogue by mi355_sed_load)
-  __device__ __forceinline__ double lhi(int j) const { return base[5 * nbm + j]; }
-  __device__ __forceinline__ double llo(int j) const { return base[6 * nbm + j]; }
+  __device__ __forceinline__ double lhi(int j) const { return f(j, kF_LHI); }
+  __device__ __forceinline__ double llo(int j) const { return f(j, kF_LLO); }
   // h nu / k in units of ln 2: the Planck argument of the fast path comes out in base 2
-  __device__ __forceinline__ double hnu2(int j) const { return base[7 * nbm + j]; }
+  __device__ __forceinline__ double hnu2(int j) const { return f(j, kF_HNU2); }
 };
+
+// max of v over the 64 lanes of the wave, as a scalar.  Every lane of the wave must be active.
+__device__ __forceinline__ int wave_max_uniform(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
 template <int MODEL>
 struct ModelTraits;
@@ -124,9 +136,9 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     // same base-2 form of the band term as the two-component branch below
     const double ae = A * exp2m1_fast(k.hk_nub2 * rT);
     double chi2 = 0.0;
-    for (int j = 0; j < B.nb; ++j) {
+    for (int j = 0; j < B.nbu; ++j) {
       const double y = B.hnu2(j) * rT;
-      const double n = exp2_fast(fma(e3, B.lhi(j), -y), 0.0) * ae, dn = 1.0 - exp2_fast(-y, 0.0);
+      const double n = exp2_fast(fma(e3, B.lhi(j), -y)) * ae, dn = 1.0 - exp2_fast(-y);
       const double r = B.d(j) - div_fast(n, dn);
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -148,11 +160,11 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double ae1 = A1 * exp2m1_fast(k.hk_nub2 * rT1);
     const double ae2 = A2 * exp2m1_fast(k.hk_nub2 * rT2);
     double chi2 = 0.0;
-    for (int j = 0; j < B.nb; ++j) {
+    for (int j = 0; j < B.nbu; ++j) {
       const double hn = B.hnu2(j), lh = B.lhi(j);
       const double y1 = hn * rT1, y2 = hn * rT2;
-      const double n1 = exp2_fast(fma(e1, lh, -y1), 0.0) * ae1, d1 = 1.0 - exp2_fast(-y1, 0.0);
-      const double n2 = exp2_fast(fma(e2, lh, -y2), 0.0) * ae2, d2 = 1.0 - exp2_fast(-y2, 0.0);
+      const double n1 = exp2_fast(fma(e1, lh, -y1)) * ae1, d1 = 1.0 - exp2_fast(-y1);
+      const double n2 = exp2_fast(fma(e2, lh, -y2)) * ae2, d2 = 1.0 - exp2_fast(-y2);
       const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -164,7 +176,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double FNiF = 0.0, FNid = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double y = B.hnu2(j) * rT;                      // base is nu itself for this model
-      const double g = div_fast(pre * exp2_fast(fma(e3, B.lhi(j), -y), 0.0), 1.0 - exp2_fast(-y, 0.0));
+      const double g = div_fast(pre * exp2_fast(fma(e3, B.lhi(j), -y)), 1.0 - exp2_fast(-y));
       const double gw = g * B.w(j);
       FNiF = fma(gw, g, FNiF);
       FNid = fma(gw, B.d(j), FNid);
@@ -194,9 +206,9 @@ __device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands&
     if (q < B.nb) {
       const int j1 = (q + 1 < B.nb) ? q + 1 : q;           // odd nb: the last band twice
       const double ya = B.hnu2(q) * rT, yb = B.hnu2(j1) * rT;
-      const double na = exp2_fast(fma(e3, B.lhi(q), -ya), 0.0) * em;
-      const double nb_ = exp2_fast(fma(e3, B.lhi(j1), -yb), 0.0) * em;
-      const double da = 1.0 - exp2_fast(-ya, 0.0), db = 1.0 - exp2_fast(-yb, 0.0);
+      const double na = exp2_fast(fma(e3, B.lhi(q), -ya)) * em;
+      const double nb_ = exp2_fast(fma(e3, B.lhi(j1), -yb)) * em;
+      const double da = 1.0 - exp2_fast(-ya), db = 1.0 - exp2_fast(-yb);
       u[q] = div_fast(na, da);
       const double ub = div_fast(nb_, db);
       u[q + 1] = (q + 1 < B.nb) ? ub : 0.0;

@@ -11,7 +11,7 @@
 namespace mi355 {
 
 struct MhArgs {
-  const double* bands;    // [S][kBandFields][nbm]
+  const double* bands;    // [S][nbm][kBandFields]
   const int32_t* nb;      // [S]
   int nbm;
   int C;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
   double th[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) th[i] = theta[i * n_eval + e];
-  Bands B{smem + (s - s_first) * stride, nbm, nb[s]};
+  Bands B{smem + (s - s_first) * stride, nbm, nb[s], nb[s]};
   double der[2];
   const double v = sed_lnlike_auto<MODEL>(th, sed_prior<MODEL>(th, k), B, k, derived ? der : nullptr);
   lnl[e] = v;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s]};
+  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s]};
   const uint64_t sbase = static_cast<uint64_t>(a.stage) << 40;
 
   double c[P], sg[P];
@@ -247,12 +247,17 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
   stage_bands(smem, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
-  if (n >= a.N) return;
-  const int64_t s = n / a.C;
+  const bool live = n < a.N;
+  const int64_t s = live ? n / a.C : s_first;
+  // band count of the lane's source and its maximum over the wave (the lanes of a wave share the
+  // source whenever C is a multiple of 64): the band loop of the fast path is scalar control flow
+  const int nb_lane = live ? a.nb[s] : 0;
+  const int nb_wave = wave_max_uniform(nb_lane);
+  if (!live) return;
 #if MI355_ABL == 3
-  Bands B{smem + (s - s_first) * stride, a.nbm, 0};
+  Bands B{smem + (s - s_first) * stride, a.nbm, 0, 0};
 #else
-  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s]};
+  Bands B{smem + (s - s_first) * stride, a.nbm, nb_lane, FAST ? nb_wave : nb_lane};
 #endif
 
   double th[P], sg[P], mu[P], m2[P];
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s]};
+  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s]};
 
   double th[P], mu[P], m2[P];
   uint32_t accb[P];
