@@ -187,7 +187,9 @@ int mi355_rng_dump(mi355_ctx* ctx, int64_t step0, int64_t nsteps, int64_t N, int
  * the accuracy tests): fn 0 exp(a), 1 expm1(a), 2 exp(a*(b+c)) with b+c a double-double
  * logarithm (= base^a), 3 a/b, 4 10^a, 5 ln(a) (a > 0, normal), 6 sin(2 pi a), 7 cos(2 pi a)
  * (a in [0,1)), 8 2^(a*(b+c)) with b+c a double-double base-2 logarithm (= base^a, the kernel
- * the SED fast path uses).  Inputs not used by fn may be null. */
+ * the one-off powers of the SED fast path use), 9 2^a by the table-driven kernel of the band and
+ * pixel loops, 10 2^a by the plain polynomial kernel (|a| < 1000).  Inputs not used by fn may be
+ * null. */
 int mi355_math_probe(mi355_ctx* ctx, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* c, double* out);
 

@@ -24,7 +24,7 @@ static const int kModelNParam[MI355_SED_NMODEL] = {3, 3, 6, 6, 2, 4, 4, 4};
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-constexpr size_t kLdsLimit = 64 * 1024;   // dynamic LDS a block may ask for without opt-in
+constexpr size_t kLdsLimit = 64 * 1024 - 512;   // dynamic LDS a block may ask for without opt-in (512 B static: the 2^y table)
 
 // LDS bytes a `bs`-chain block needs for the band tables of the sources it can touch
 static size_t lds_bytes(int bs, int C, int nbm, int64_t nsources) {
@@ -761,7 +761,7 @@ int mi355_gauss_quadform(mi355_ctx* c, int64_t m, int64_t n, const double* A, co
 int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* cc, double* out) {
   MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
-  MI355_REQUIRE(fn >= 0 && fn <= 8, "mi355_math_probe: unknown function %d", fn);
+  MI355_REQUIRE(fn >= 0 && fn <= 10, "mi355_math_probe: unknown function %d", fn);
   MI355_REQUIRE((fn != 2 && fn != 3) || b, "mi355_math_probe: b required");
   MI355_REQUIRE(fn != 2 || cc, "mi355_math_probe: c required");
   MI355_HIP(hipSetDevice(c->device));

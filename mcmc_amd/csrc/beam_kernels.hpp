@@ -70,8 +70,8 @@ __device__ __forceinline__ double beam_model_at(const double* k, double x, doubl
 // beam_model_at, costs 22).  The reassociation moves a model value by a few ulp, far inside the
 // 1e-12 budget of lnL (tests/test_beam_gpu.py).
 // The exponent is produced directly in base 2 (the folded C^-1 carries log2 e), so the
-// exponential needs no argument scaling: 2^y = 2^n (1 + P(y - n)), P = expm1(f ln 2) as one
-// degree-11 Horner chain (fastmath.hpp: exp2m1_over_f).
+// exponential needs no argument scaling: the table-driven 2^y of fastmath.hpp (exp2_tab_n), the
+// 8 chains of a pixel interleaved.
 //  f[0..1] centre, f[2] -Cxx/2 log2e, f[3] -Cyy/2 log2e, f[4] -Cxy log2e, f[5] offset,
 //  f[6..7] plane gradient, f[8] amplitude
 __device__ __forceinline__ void beam_fold(const double* k, double* f) {
@@ -87,27 +87,32 @@ __device__ __forceinline__ void beam_fold(const double* k, double* f) {
   f[8] = k[5];
 }
 
-// 2^y for y <= ~1000 (no upper clamp: the exponent of a positive-definite form is <= 0)
-__device__ __forceinline__ double exp2_nonpos(double y) {
-  y = fmax(y, -1080.0);
-  const double fn = rint(y);
-  const double f = y - fn;                                           // exact, |f| <= 1/2
-  const double p = exp2m1_over_f(f);
-  return ldexp(fma(p, f, 1.0), static_cast<int>(fn));
-}
-
 template <bool WPIX>
-__device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], double x, double y,
-                                                double dv, double w, double* acc) {
+__device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], const double* e2t,
+                                                double x, double y, double dv, double w,
+                                                double* acc) {
+  constexpr int G = 4;                                     // chains interleaved at a time
 #pragma unroll
-  for (int c = 0; c < kBeamCH; ++c) {
-    const double dx = x - f[c][0], dy = y - f[c][1];
-    const double u = fma(f[c][4], dy, f[c][2] * dx);
-    const double arg = fma(dx, u, (f[c][3] * dy) * dy);
-    const double g = exp2_nonpos(arg);
-    const double v = fma(dx, f[c][6], fma(dy, f[c][7], g + f[c][5]));
-    const double r = fma(-f[c][8], v, dv);
-    acc[c] = WPIX ? fma(r * w, r, acc[c]) : fma(r, r, acc[c]);
+  for (int c0 = 0; c0 < kBeamCH; c0 += G) {
+    double dx[G], dy[G], arg[G], g[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int c = c0 + i;
+      dx[i] = x - f[c][0];
+      dy[i] = y - f[c][1];
+      const double u = fma(f[c][4], dy[i], f[c][2] * dx[i]);
+      // the exponent of a positive-definite form is <= 0; the clamp keeps 2^arg a normal number
+      // (exp2_tab_n adds the power of two to the exponent field)
+      arg[i] = fmax(fma(dx[i], u, (f[c][3] * dy[i]) * dy[i]), -1000.0);
+    }
+    exp2_tab_n<G>(arg, e2t, g);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int c = c0 + i;
+      const double v = fma(dx[i], f[c][6], fma(dy[i], f[c][7], g[i] + f[c][5]));
+      const double r = fma(-f[c][8], v, dv);
+      acc[c] = WPIX ? fma(r * w, r, acc[c]) : fma(r, r, acc[c]);
+    }
   }
 }
 
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
   __shared__ double fc[kBeamCH][kBeamNF];
   __shared__ double red[4][kBeamCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double* e2t = stage_exp2_table();              // valid after the barrier below
   const int64_t ml = blockIdx.y;                       // map within this call
   const int64_t m = a.m0 + ml;
   const int grp = blockIdx.z;                          // chain group
@@ -174,10 +180,10 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
   const double w_shared = (a.w_kind == 2) ? 0.0 : ws[0];
   if (!irregular && a.w_kind == 2) {
     for (int64_t p = p0 + tid; p < p1; p += 256)
-      beam_pixel_fast<true>(fc, xs[p], ys[p], ds[p], ws[p], acc);   // GaussianData.py:47
+      beam_pixel_fast<true>(fc, e2t, xs[p], ys[p], ds[p], ws[p], acc);   // GaussianData.py:47
   } else if (!irregular) {
     for (int64_t p = p0 + tid; p < p1; p += 256)                    // one weight: taken out of the sum
-      beam_pixel_fast<false>(fc, xs[p], ys[p], ds[p], 0.0, acc);
+      beam_pixel_fast<false>(fc, e2t, xs[p], ys[p], ds[p], 0.0, acc);
 #pragma unroll
     for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
   } else {

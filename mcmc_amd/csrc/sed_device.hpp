@@ -20,6 +20,7 @@ struct Bands {
   // that the band loop is scalar control flow.  Rows nb <= j < nbm of a table are padding with
   // weight 0 and benign values (nu = nu_b, d = 0): they add exactly 0 to a chi-square.
   int nbu;
+  const double* e2t;   // stage_exp2_table() of the block: the 2^y kernel of the fast path
   __device__ __forceinline__ double f(int j, int field) const { return base[j * kBandFields + field]; }
   __device__ __forceinline__ double nu(int j) const { return f(j, kF_NU); }
   __device__ __forceinline__ double hnu(int j) const { return f(j, kF_HNU); }      // h/k * nu
@@ -138,7 +139,10 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double chi2 = 0.0;
     for (int j = 0; j < B.nbu; ++j) {
       const double y = B.hnu2(j) * rT;
-      const double n = exp2_fast(fma(e3, B.lhi(j), -y)) * ae, dn = 1.0 - exp2_fast(-y);
+      const double z[2] = {fma(e3, B.lhi(j), -y), -y};
+      double pw[2];
+      exp2_tab_n<2>(z, B.e2t, pw);
+      const double n = pw[0] * ae, dn = 1.0 - pw[1];
       const double r = B.d(j) - div_fast(n, dn);
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -163,8 +167,11 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     for (int j = 0; j < B.nbu; ++j) {
       const double hn = B.hnu2(j), lh = B.lhi(j);
       const double y1 = hn * rT1, y2 = hn * rT2;
-      const double n1 = exp2_fast(fma(e1, lh, -y1)) * ae1, d1 = 1.0 - exp2_fast(-y1);
-      const double n2 = exp2_fast(fma(e2, lh, -y2)) * ae2, d2 = 1.0 - exp2_fast(-y2);
+      const double z[4] = {fma(e1, lh, -y1), -y1, fma(e2, lh, -y2), -y2};
+      double pw[4];
+      exp2_tab_n<4>(z, B.e2t, pw);
+      const double n1 = pw[0] * ae1, d1 = 1.0 - pw[1];
+      const double n2 = pw[2] * ae2, d2 = 1.0 - pw[3];
       const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
@@ -206,9 +213,11 @@ __device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands&
     if (q < B.nb) {
       const int j1 = (q + 1 < B.nb) ? q + 1 : q;           // odd nb: the last band twice
       const double ya = B.hnu2(q) * rT, yb = B.hnu2(j1) * rT;
-      const double na = exp2_fast(fma(e3, B.lhi(q), -ya)) * em;
-      const double nb_ = exp2_fast(fma(e3, B.lhi(j1), -yb)) * em;
-      const double da = 1.0 - exp2_fast(-ya), db = 1.0 - exp2_fast(-yb);
+      const double z[4] = {fma(e3, B.lhi(q), -ya), -ya, fma(e3, B.lhi(j1), -yb), -yb};
+      double pw[4];
+      exp2_tab_n<4>(z, B.e2t, pw);
+      const double na = pw[0] * em, da = 1.0 - pw[1];
+      const double nb_ = pw[2] * em, db = 1.0 - pw[3];
       u[q] = div_fast(na, da);
       const double ub = div_fast(nb_, db);
       u[q + 1] = (q + 1 < B.nb) ? ub : 0.0;

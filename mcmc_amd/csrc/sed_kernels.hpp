@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
   const int64_t e_last = min(e0 + blockDim.x, n_eval) - 1;
   const int64_t s_first = s0 + e0 / C;
   const int nsrc = static_cast<int>(s0 + e_last / C - s_first) + 1;
+  const double* e2t = stage_exp2_table();
   stage_bands(smem, bands, s_first, nsrc, stride);
   const int64_t e = e0 + threadIdx.x;
   if (e >= n_eval) return;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
   double th[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) th[i] = theta[i * n_eval + e];
-  Bands B{smem + (s - s_first) * stride, nbm, nb[s], nb[s]};
+  Bands B{smem + (s - s_first) * stride, nbm, nb[s], nb[s], e2t};
   double der[2];
   const double v = sed_lnlike_auto<MODEL>(th, sed_prior<MODEL>(th, k), B, k, derived ? der : nullptr);
   lnl[e] = v;
@@ -141,11 +142,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
   const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  const double* e2t = stage_exp2_table();
   stage_bands(smem, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s]};
+  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s], e2t};
   const uint64_t sbase = static_cast<uint64_t>(a.stage) << 40;
 
   double c[P], sg[P];
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  const double* e2t = stage_exp2_table();
   stage_bands(smem, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
   const bool live = n < a.N;
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int nb_wave = wave_max_uniform(nb_lane);
   if (!live) return;
 #if MI355_ABL == 3
-  Bands B{smem + (s - s_first) * stride, a.nbm, 0, 0};
+  Bands B{smem + (s - s_first) * stride, a.nbm, 0, 0, e2t};
 #else
-  Bands B{smem + (s - s_first) * stride, a.nbm, nb_lane, FAST ? nb_wave : nb_lane};
+  Bands B{smem + (s - s_first) * stride, a.nbm, nb_lane, FAST ? nb_wave : nb_lane, e2t};
 #endif
 
   double th[P], sg[P], mu[P], m2[P];
@@ -419,11 +422,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
   const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
+  const double* e2t = stage_exp2_table();
   stage_bands(tables, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s]};
+  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s], e2t};
 
   double th[P], mu[P], m2[P];
   uint32_t accb[P];
@@ -574,6 +578,8 @@ __global__ void k_rng_dump(uint64_t seed, int64_t step0, int64_t nsteps, int64_t
 __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b, const double* c,
                              double* out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const double* tab = stage_exp2_table();
+  __syncthreads();
   if (i >= n) return;
   double v;
   switch (fn) {
@@ -585,6 +591,8 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
     case 6: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = sn; break; }
     case 7: { double sn, cs; sincos2pi_fast(a[i], &sn, &cs); v = cs; break; }
     case 8: v = pow2_prelog(a[i], b[i], c[i]); break;
+    case 9: v = exp2_tab(a[i], tab); break;
+    case 10: v = exp2_fast(a[i]); break;
     default: v = exp10_fast(a[i]); break;
   }
   out[i] = v;

@@ -110,3 +110,23 @@ def test_box_muller_kernels(eng):
     # absolute accuracy is what the normals need (the exact values cross zero)
     assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(sn, es)) <= 3e-16
     assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(cs, ec)) <= 3e-16
+
+
+def test_exp2_kernels_of_the_band_loop(eng):
+    """2^y as the SED band loop and the beam pixel loop evaluate it: the table-driven kernel
+    (exp2_tab: 64-entry table, degree-4 polynomial, integer exponent arithmetic) and the plain
+    degree-11 chain (exp2_fast), on the whole range the fast path admits, at the table's grid
+    points k/64 and next to the rounding boundaries (k + 1/2)/64."""
+    rng = np.random.default_rng(9)
+    k = rng.integers(-64 * 900, 64 * 900, 600)
+    y = np.concatenate([rng.uniform(-1000, 1000, 4000), rng.uniform(-1, 1, 2000), k / 64.0,
+                        np.nextafter((k + 0.5) / 64.0, 0), np.nextafter((k + 0.5) / 64.0, 1e9),
+                        [0.0, -0.0, 1e-300, -1e-300, 999.9, -999.9, 1 / 64, -1 / 64]])
+    exact = [mp.power(2, mp.mpf(float(v))) for v in y]
+    w = ulp_err(eng.math_probe(9, y), exact)
+    print("exp2_tab: max %.2f ulp" % w)
+    assert w <= 1.4
+    w = ulp_err(eng.math_probe(10, y), exact)
+    print("exp2_fast: max %.2f ulp" % w)
+    assert w <= 1.2
+    np.testing.assert_array_equal(eng.math_probe(9, np.arange(-64.0, 65.0)), 2.0 ** np.arange(-64.0, 65.0))
