@@ -378,3 +378,56 @@ def test_catalogue_outside_the_fast_path_domain(eng, mid):
     ch.run(30)
     np.testing.assert_allclose(tr[:, s, c], np.asarray(ch.samples)[1:], rtol=1e-12)
     np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
+
+
+def test_sed_abi_errors_leave_the_context_usable():
+    """Misuse of the SED / MH entry points returns an error with a message (never a fault), and
+    the context keeps working afterwards."""
+    from mcmc_amd import Engine
+    import ctypes as C
+    from mcmc_amd._lib import Mi355Error, check
+    nu, d, sig, truth = R.synth_sed_catalogue(2, seed=1)
+    nb = np.array([8, 8], np.int32)
+    with Engine() as e:
+        with pytest.raises(Mi355Error, match="not initialised"):
+            e.mh_run(10)                                                        # nothing loaded yet
+        with pytest.raises(Mi355Error, match="outside"):
+            e.sed_load(R.M2N, np.array([8, 9], np.int32), nu, d, sig)          # nb > nb_max
+        bad = nu.copy()
+        bad[1, 3] = -5.0
+        with pytest.raises(Mi355Error, match="out of range"):
+            e.sed_load(R.M2N, nb, bad, d, sig)                                  # negative frequency
+        bad[1, 3] = np.nan
+        with pytest.raises(Mi355Error, match="out of range"):
+            e.sed_load(R.M2N, nb, bad, d, sig)
+        with pytest.raises(Mi355Error, match="unknown SED model"):
+            m = e.default_model(R.M2N)
+            m.model = 99
+            e.sed_load(R.M2N, nb, nu, d, sig, consts=m)
+        e.sed_load(R.M2N, nb, nu, d, sig)
+        with pytest.raises(Mi355Error, match="not initialised"):
+            e.mh_run(10)
+        with pytest.raises(Mi355Error, match="not initialised"):
+            e.mh_moments()
+        with pytest.raises(Mi355Error, match="nblock=8 outside"):
+            e.mh_init(4, truth[0], np.full(6, 0.01), param_blocks=np.array([0, 1, 2, 3, 4, 7]),
+                      randomize_start=False)
+        e.mh_init(4, truth[0], np.full(6, 0.01), param_blocks=np.arange(6), randomize_start=False)
+        with pytest.raises(Mi355Error, match="no samples"):
+            e.mh_adapt()
+        with pytest.raises(Mi355Error, match="negative"):
+            e.mh_run(-1)
+        with pytest.raises(Mi355Error):                                        # normals without uniforms
+            z = np.zeros((5, 8, 6))
+            check(e.lib.mi355_mh_run(e._h, 5, 1, z.ctypes.data_as(C.POINTER(C.c_double)), None))
+        e.mh_run(12)
+        with pytest.raises(Mi355Error, match="kept no trace"):
+            e.mh_trace()
+        with pytest.raises(Mi355Error, match="trace rows"):
+            e.mh_ess()
+        # still in working order: the chain equals a fresh run of the same stream position
+        got = e.sed_lnlike(np.broadcast_to(truth[:, None, :], (2, 3, 6)).copy())
+        for s in range(2):
+            ref = R.sed_lnlike(R.M2N, truth[s], R.GaussData(nu[s], d[s], sig[s]))
+            assert_lnl_close(got[s], np.full(3, ref), RTOL_LNL)
+        assert e.mh_moments()["naccept"].shape == (2, 4)
