@@ -140,8 +140,14 @@ def main():
     eng.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                 randomize_start=True)
     # stage 0 with the production driver's proposal widths, then newMCMC(): sigma = 2.4/sqrt(6)*stdev
+    # (run as launches of `inner` steps like the timed ones, so that every k_mh_run launch of a
+    # profile of this command does the same work and rocprofv3's per-kernel average is the figure
+    # the roofline uses)
     if args.adapt > 0:
-        eng.mh_run(args.adapt)
+        left = args.adapt
+        while left > 0:
+            eng.mh_run(min(inner, left))
+            left -= min(inner, left)
         eng.mh_adapt()
 
     def one_step():
