@@ -152,7 +152,7 @@ def main():
 
     def one_step():
         eng.mh_run(inner)
-        return D.engine_rhat(eng)
+        return D.engine_rhat(eng, Ctot=C * world)
 
     def barrier():
         if world > 1:

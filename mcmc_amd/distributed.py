@@ -52,7 +52,7 @@ def allreduce_sum_(t, group=None):
     return t
 
 
-def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None):
+def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None, Ctot=None):
     """Chain-sharded Gelman-Rubin.
 
     partial(pass_, gmean, out): fill `out` with this rank's sums over its C_local chains:
@@ -61,11 +61,13 @@ def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None):
     Both operate on torch float64 tensors resident on `device`; on a GPU they are the HIP
     kernels behind mi355_rhat_partial_async / mi355_rhat_finish_async.  Centred second pass:
     sum(mean^2) - (sum mean)^2/C would cancel catastrophically in FP64.
+    Ctot: the number of chains per source over all ranks if the caller already knows it (it is
+    all-reduced here otherwise: one more collective and a host round trip per call).
     Returns (rhat [S,P] tensor, Ctot)."""
-    W = _world(group)
-    Ctot = torch.tensor([float(C_local)], dtype=torch.float64, device=device)
-    allreduce_sum_(Ctot, group)
-    Ctot = int(round(float(Ctot.item())))
+    if Ctot is None:
+        t = torch.tensor([float(C_local)], dtype=torch.float64, device=device)
+        allreduce_sum_(t, group)
+        Ctot = int(round(float(t.item())))
     s0 = torch.empty((P, S), dtype=torch.float64, device=device)
     partial(0, None, s0)
     allreduce_sum_(s0, group)
@@ -78,9 +80,11 @@ def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None):
     return out.t().contiguous(), Ctot
 
 
-def engine_rhat(engine, group=None):
+def engine_rhat(engine, group=None, Ctot=None):
     """R-hat of every loaded source over the chains of all ranks in `group` (chain-sharded
-    layout); with one rank this equals Engine.rhat().  Returns a [S,P] CUDA tensor."""
+    layout); with one rank this equals Engine.rhat().  Ctot: chains per source over all ranks
+    when every rank knows it (saves a collective and a host round trip per call; all ranks must
+    pass it or none).  Returns a [S,P] CUDA tensor."""
     device = torch.device("cuda", engine.device)
 
     def partial(pass_, gmean, out):
@@ -93,5 +97,6 @@ def engine_rhat(engine, group=None):
         engine.rhat_finish(sums.data_ptr(), Ctot, out.data_ptr())
         engine.sync()
 
-    rhat, _ = gelman_rubin_allreduce(partial, finish, engine.C, engine.P, engine.S, device, group)
+    rhat, _ = gelman_rubin_allreduce(partial, finish, engine.C, engine.P, engine.S, device, group,
+                                     Ctot=Ctot)
     return rhat
