@@ -21,12 +21,12 @@ pytestmark = pytest.mark.gpu
 def test_sed_full_size_chains_match_oracle_on_a_sample(S, C):
     """C2 (1e5 sources x 64 chains) and what one of 8 GPUs holds of C3 in the chain-sharded layout
     (all 1e6 sources x 32 of the 256 chains: 3.2e7 chains, 7.3 GB of chain state).
-    Free-running chains, 4 block cycles: every 9973rd chain (first and last included)
+    Free-running chains, 20 block cycles: every 9973rd chain (first and last included)
     equals the vectorised oracle (tests/test_oracle_vector.py pins it to the scalar restatement)
     on the same Philox draws - decisions identical, position / lnPr to 1e-12 - and its running
     moments; R-hat of all sources equals the NumPy formula on the device's own moments."""
     from mcmc_amd import Engine, synth
-    P, nsteps = 6, 24
+    P, nsteps = 6, 120
     nu, d, sig, truth = synth.sed_catalogue(S)
     nb = np.full(S, nu.shape[1], np.int32)
     rng = np.random.default_rng(11)
@@ -63,7 +63,7 @@ def test_sed_full_size_chains_match_oracle_on_a_sample(S, C):
     np.testing.assert_allclose(flat["theta"][pick], vc.theta, rtol=1e-12)
     np.testing.assert_allclose(flat["lnPr"][pick], vc.lnPr, rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(flat["mean"][pick], traj.mean(axis=0), rtol=1e-12)
-    # a parameter whose four proposals were all rejected: exactly 0 on the device, rounding of
+    # a parameter whose proposals were all rejected: exactly 0 on the device, rounding of
     # sum/n (~1e-28) in NumPy's two-pass formula, hence the absolute floor
     np.testing.assert_allclose(flat["var"][pick], traj.var(axis=0), rtol=1e-8, atol=1e-20)
     assert 0.02 < (vc.naccept.mean() - 1) / nsteps < 0.98      # chains moved and were rejected
