@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
       const double mu = a.mean[i * N + n];
       const double dlt = x - mu;
       d[i * t.cb + t.cl] = dlt;
-      const double mu1 = mu + dlt * rn;
+      const double mu1 = fma(dlt, rn, mu);                // the same FMAs as the fused kernel
       a.mean[i * N + n] = mu1;
-      a.m2[i * N + n] += dlt * (x - mu1);
+      a.m2[i * N + n] = fma(dlt, x - mu1, a.m2[i * N + n]);
       if (a.tr_theta) a.tr_theta[i * N + n] = x;
     }
   }

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const double dlt = th[i] - mu[i];
-      mu[i] += dlt * rn;
-      m2[i] += dlt * (th[i] - mu[i]);
+      mu[i] = fma(dlt, rn, mu[i]);
+      m2[i] = fma(dlt, th[i] - mu[i], m2[i]);
     }
 #endif
     if (a.thin > 0) {
@@ -537,8 +537,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const double dlt = th[i] - mu[i];
-      mu[i] += dlt * rn;
-      m2[i] += dlt * (th[i] - mu[i]);
+      mu[i] = fma(dlt, rn, mu[i]);
+      m2[i] = fma(dlt, th[i] - mu[i], m2[i]);
     }
     if (a.thin > 0) {
       if (++thin_ctr == a.thin) {
