@@ -1019,9 +1019,69 @@ def golden_clfiles(R):
 
 
 
+class _StubLike:
+    """like / like.model of a finished chain, as getdist_ahj's consistency check uses them: lnLike
+    and chi2 of a stored sample are looked up (off by `skew` to exercise the 1 % assertion)."""
+    nDerived = 0
+
+    class model:
+        @staticmethod
+        def prior(*p):
+            return 1.0
+
+    def __init__(self, samples, lnPr, skew=1.0):
+        self.tab = {tuple(np.round(s, 12)): l for s, l in zip(samples, lnPr)}
+        self.skew = skew
+
+    def lnLike(self, p):
+        return self.skew * self.tab[tuple(np.round(np.asarray(p), 12))]
+
+    def chi2(self, p):
+        return -2.0 * self.tab[tuple(np.round(np.asarray(p), 12))]
+
+
+def golden_getdist(R):
+    """G9: MCMC/getdist_ahj.py's numeric half (printvals, histgrid(noPlot), getallsamples,
+    GaussPDF, stddev) on stub chains: return values and printed text."""
+    import contextlib
+    import io
+    import json
+    g = importlib.import_module("MCMC.getdist_ahj")
+    rng = np.random.default_rng(909)
+    cases = {}
+    for name, (n, p, nder, skew) in {"plain": (60, 3, 0, 1.0), "derived": (45, 2, 2, 1.004),
+                                      "skewed": (30, 2, 0, 1.02)}.items():
+        samples = rng.normal(1.0, 2.0, (n, p))
+        lnPr = -0.5 * ((samples - 1.0) ** 2).sum(axis=1) - 3.0
+        derived = rng.normal(size=(n, nder)) if nder else None
+        m = types.SimpleNamespace(samples=samples, lnPr=lnPr, nDerived=nder, derived=derived)
+        full = np.hstack([samples, derived]) if nder else samples
+        # the looked-up point is a row of samples+derived columns: key on the parameter columns
+        like = _StubLike(full, lnPr, skew)
+        m.like = like
+        out = dict(samples=samples.tolist(), lnPr=lnPr.tolist(), nDerived=nder, skew=skew,
+                   derived=derived.tolist() if nder else None)
+        for fn, kw in (("printvals", {}), ("histgrid", dict(noPlot=True, burn=0.2, stride=2))):
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    r = getattr(g, fn)(m, **kw)
+                out[fn] = dict(ret=[float(r[0]), np.asarray(r[1]).tolist()], text=buf.getvalue())
+            except AssertionError as e:
+                out[fn] = dict(raises=str(e), text=buf.getvalue())
+        out["getallsamples"] = g.getallsamples(m, burn=7, stride=3).tolist()
+        cases[name] = out
+    x = np.linspace(-3, 4, 9)
+    misc = dict(x=x.tolist(), gauss=g.GaussPDF(x, 0.5, 2.0).tolist(),
+                stddev=float(g.stddev(np.arange(7.0) ** 2)), key=g.key("chain_EE_3.txt"))
+    with open(os.path.join(OUT, "getdist_g9.json"), "w") as f:
+        json.dump(dict(ref_sha=ref_tree_sha(), cases=cases, misc=misc), f, indent=1)
+    print("wrote getdist_g9.json")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -1033,6 +1093,8 @@ def main():
         golden_readers(R)
     if "clfiles" in which:
         golden_clfiles(R)
+    if "getdist" in which:
+        golden_getdist(R)
 
 
 if __name__ == "__main__":
