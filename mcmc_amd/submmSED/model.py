@@ -35,11 +35,46 @@ def _model_engine(model_id):
     key = (model_id,) + tuple(sorted(device_constants().items()))
     eng = _ENGINES.get(key)
     if eng is None:
+        while len(_ENGINES) >= 16:                          # (distinct constants are rare: bounded anyway)
+            _ENGINES.pop(next(iter(_ENGINES))).close()
         eng = Engine()
         one = np.ones((1, 1))
         eng.sed_load(model_id, np.ones(1, np.int32), one * nu_b, one, one, consts=device_constants())
         _ENGINES[key] = eng
     return eng
+
+
+def _flux_engine(model_id, nu_norm):
+    """Engine for the module-level Planck functions: the normalisation frequency of a call is the
+    nu_b of its device constants (model.py:107-109 normalises at the argument nu_norm)."""
+    global nu_b
+    if not nu_norm:
+        return _model_engine(model_id)
+    saved = nu_b
+    try:
+        nu_b = float(nu_norm)
+        return _model_engine(model_id)
+    finally:
+        nu_b = saved
+
+
+def greybody(beta, T, nu, nu_norm=False):
+    """Greybody flux at frequency nu [GHz] for temperature T [K], evaluated by the HIP library
+    (mi355_sed_flux): (nu/nu_norm)^(3+beta) expm1(h nu_norm/kT)/expm1(h nu/kT) when nu_norm is
+    given, prefac nu_b^-beta nu^(3+beta)/expm1(h nu/kT) otherwise; an overflowing expm1 gives 0
+    as in the reference.  model.py:97-111"""
+    nu_arr = np.asarray(nu, dtype=np.float64)
+    if nu_norm:
+        out = _flux_engine("M1N", nu_norm).sed_flux(np.array([1.0, beta, T]), nu_arr.reshape(-1))
+    else:
+        out = _flux_engine("M1", False).sed_flux(np.array([beta, T], np.float64), nu_arr.reshape(-1))
+    return out.reshape(nu_arr.shape) if nu_arr.ndim else float(out[0])
+
+
+def blackbody(T, nu, nu_norm=False):
+    """Blackbody flux: the greybody with beta = 0 (nu_b^-0 = 1 and the exponent 3+0 are exact, so
+    this is model.py:80-94 operation for operation)."""
+    return greybody(0.0, T, nu, nu_norm=nu_norm)
 
 
 def _greybody_host(beta, T, nu, nu_norm=False):

@@ -431,3 +431,24 @@ def test_sed_abi_errors_leave_the_context_usable():
             ref = R.sed_lnlike(R.M2N, truth[s], R.GaussData(nu[s], d[s], sig[s]))
             assert_lnl_close(got[s], np.full(3, ref), RTOL_LNL)
         assert e.mh_moments()["naccept"].shape == (2, 4)
+
+
+def test_module_level_planck_functions_match_reference_grids(g1):
+    """model.greybody / model.blackbody (model.py:80-111) as module-level functions over the HIP
+    library, on the reference's own (beta, T, nu) grids of G1: normalised and un-normalised forms,
+    T down to the prior edge, the overflowing expm1 that must give exactly 0."""
+    from mcmc_amd.submmSED import model as M
+    beta, T, nu = g1["beta"], g1["T"], g1["nu"]
+    for j, t in enumerate(T):
+        for i, b in enumerate(beta):
+            assert_lnl_close(M.greybody(b, t, nu, nu_norm=M.nu_b), g1["grey_norm"][i, j], RTOL_LNL,
+                             "greybody norm beta=%g T=%g" % (b, t))
+            assert_lnl_close(M.greybody(b, t, nu), g1["grey_unnorm"][i, j], RTOL_LNL,
+                             "greybody beta=%g T=%g" % (b, t))
+        assert_lnl_close(M.blackbody(t, nu, nu_norm=M.nu_b), g1["bb_norm"][j], RTOL_LNL, "blackbody norm")
+        assert_lnl_close(M.blackbody(t, nu), g1["bb_unnorm"][j], RTOL_LNL, "blackbody")
+    assert M.greybody(0.0, 3.0, 60000.0, nu_norm=M.nu_b) == 0.0          # scalar in, scalar out
+    # a normalisation frequency other than the module's nu_b (oracle restatement of :107-109)
+    got = M.greybody(1.5, 20.0, nu, nu_norm=353.0)
+    assert_lnl_close(got, R.greybody(1.5, 20.0, nu, nu_norm=353.0), RTOL_LNL)
+    assert M.nu_b == 1000.0
