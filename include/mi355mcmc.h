@@ -285,6 +285,12 @@ int mi355_beam_prior_package(mi355_ctx* ctx, int64_t n, const double* theta, dou
  * Needs no maps. */
 int mi355_beam_model(mi355_ctx* ctx, int64_t n, const double* theta, int64_t npts, const double* x,
                      const double* y, double* out);
+/* gauss2d(x, y, x0, y0, Cinv_xx, Cinv_xy, Cinv_yy) = exp(-(dx^2 Cxx + dy^2 Cyy + 2 dx dy Cxy)/2)
+ * (BeamModel.py:288-290; what GaussianBeamModel2D.at / atxy return, :152-160) for n points with the
+ * packed inverse covariance given (set_Cinv, :128-136, is scalar work of the caller).  Host
+ * pointers x, y [n] -> out [n].  Needs no loaded maps. */
+int mi355_beam_gauss2d(mi355_ctx* ctx, int64_t n, const double* x, const double* y, double x0,
+                       double y0, double cinv_xx, double cinv_xy, double cinv_yy, double* out);
 /* BeamData.stats(sigcut, do_abs) of map m (BeamData.py:35-71): out host [4] = <x>, <y>, var x,
  * var y weighted by the mean-subtracted data (has_sigcut=0 means sigcut=None). */
 int mi355_beam_stats(mi355_ctx* ctx, int64_t m, int32_t has_sigcut, double sigcut, int32_t do_abs,

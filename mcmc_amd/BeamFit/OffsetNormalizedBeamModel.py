@@ -44,13 +44,24 @@ class OffsetNormalizedBeamModel(G2D):
     @classmethod
     def _prior_engine(cls):
         """engine holding a snapshot of the class-level prior state (reloaded when it changes)"""
+        return OffsetNormalizedBeamModel._prior_engine_for(cls)
+
+    _prior_engines = {}
+
+    @staticmethod
+    def _prior_engine_for(cls):
+        """the same for any class of the GaussianBeamModel2D family (each has its own class-level
+        prior state)"""
         from ..engine import Engine
         key = str(cls.prior_state())
-        if cls._prior_eng is None or cls._prior_key != key:
+        have = OffsetNormalizedBeamModel._prior_engines.get(cls)
+        if have is None or have[1] != key:
+            if have is not None:
+                have[0].close()
             eng = Engine()
             eng.beam_load(np.zeros(1), np.zeros(1), np.zeros((1, 1)), 1.0, **cls.prior_state())
-            cls._prior_eng, cls._prior_key = eng, key
-        return cls._prior_eng
+            have = OffsetNormalizedBeamModel._prior_engines[cls] = (eng, key)
+        return have[0]
 
     @classmethod
     def prior(cls, center, sigmas, angle, amplitude, plane):         # :93-101, BeamModel.py:165-187
@@ -71,3 +82,18 @@ class OffsetNormalizedBeamModel(G2D):
     proposal = Proposal.GenericGaussianProposal(package=package, unpackage=unpackage)
     unpackage = staticmethod(unpackage)
     package = staticmethod(package)
+
+
+def planexy(mu, phi, x, y):                                          # :146-152
+    """z coordinate of a plane with normal vector (mu = cos(theta), phi) at (x, y).  Host-side
+    helper with the reference's operation order; inside the likelihood the plane term is part of
+    the beam kernels (csrc/beam_device.hpp)."""
+    if mu == 1:
+        return 0
+    return np.sqrt(1 / mu / mu - 1) * (x * np.cos(phi) + y * np.sin(phi))
+
+
+def plane(mu, phi, data):                                            # :156-167 ("Not used!")
+    if mu == 1:
+        return 0
+    return np.sqrt(1 - mu * mu) / mu * (data.x * np.cos(phi) + data.y * np.sin(phi))

@@ -99,6 +99,8 @@ SIGNATURES = {
     "mi355_beam_prior_package": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p]),
     "mi355_beam_model": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_int64, c_double_p, c_double_p,
                                    c_double_p]),
+    "mi355_beam_gauss2d": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, c_double_p]),
     "mi355_beam_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, c_double_p]),
     "mi355_mh_init_problem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32,
                                         c_double_p, C.c_int32, c_int32_p, C.c_int32, C.c_int32,

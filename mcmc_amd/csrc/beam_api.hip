@@ -199,6 +199,24 @@ int mi355_beam_model(mi355_ctx* c, int64_t n, const double* theta, int64_t npts,
   return 0;
 }
 
+int mi355_beam_gauss2d(mi355_ctx* c, int64_t n, const double* x, const double* y, double x0,
+                       double y0, double cinv_xx, double cinv_xy, double cinv_yy, double* out) {
+  MI355_REQUIRE(c && x && y && out && n > 0, "mi355_beam_gauss2d: bad argument");
+  MI355_HIP(hipSetDevice(c->device));
+  const size_t np = static_cast<size_t>(n);
+  if (c->scratch_a.alloc(2 * np) || c->scratch_b.alloc(np)) return -2;
+  double* dx = c->scratch_a.p;
+  double* dy = dx + np;
+  MI355_HIP(hipMemcpyAsync(dx, x, np * 8, hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipMemcpyAsync(dy, y, np * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_beam_gauss2d, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
+                     c->stream, n, dx, dy, x0, y0, cinv_xx, cinv_xy, cinv_yy, c->scratch_b.p);
+  MI355_HIP(hipGetLastError());
+  MI355_HIP(hipMemcpyAsync(out, c->scratch_b.p, np * 8, hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int mi355_beam_stats(mi355_ctx* c, int64_t m, int32_t has_sigcut, double sigcut, int32_t do_abs,
                      double* out) {
   if (beam_ready(c, "mi355_beam_stats")) return -1;

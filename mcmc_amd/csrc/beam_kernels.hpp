@@ -253,6 +253,16 @@ __global__ void k_beam_model(int64_t n, const double* __restrict__ theta, int64_
   out[e] = beam_model_at<true>(k, x[ip], y[ip]);
 }
 
+// gauss2d (BeamModel.py:288-290) with the packed C^-1 given, in the reference's operation order
+__global__ void k_beam_gauss2d(int64_t n, const double* __restrict__ x, const double* __restrict__ y,
+                               double x0, double y0, double cxx, double cxy, double cyy,
+                               double* __restrict__ out) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const double dx = x[e] - x0, dy = y[e] - y0;
+  out[e] = exp(-0.5 * (dx * dx * cxx + dy * dy * cyy + 2 * dx * dy * cxy));
+}
+
 // BeamData.stats (BeamData.py:35-71), one block: pass 0 sum(d) -> mean; pass 1 the five
 // data-weighted sums over the pixels with d - mean > sigcut*sig (all pixels if !has_cut).
 __global__ __launch_bounds__(256) void k_beam_stats(int64_t npix, const double* __restrict__ x,

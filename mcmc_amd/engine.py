@@ -525,6 +525,17 @@ class Engine:
         check(self.lib.mi355_beam_model(self._h, flat.shape[0], _dp(flat), x.size, _dp(x), _dp(y), _dp(out)))
         return out[0] if single else out
 
+    def beam_gauss2d(self, x, y, x0, y0, cxx, cxy, cyy):
+        """gauss2d of BeamModel.py:288-290 at the points (x, y) for a packed inverse covariance"""
+        x = _f64(x)
+        shape = x.shape
+        x = np.ascontiguousarray(x.reshape(-1))
+        y = _f64(np.broadcast_to(np.asarray(y, np.float64), shape)).reshape(-1)
+        out = np.empty(x.size)
+        check(self.lib.mi355_beam_gauss2d(self._h, x.size, _dp(x), _dp(y), float(x0), float(y0),
+                                          float(cxx), float(cxy), float(cyy), _dp(out)))
+        return out.reshape(shape)
+
     def beam_stats(self, m=0, sigcut=None, do_abs=False):
         out = np.empty(4)
         check(self.lib.mi355_beam_stats(self._h, int(m), int(sigcut is not None),

@@ -1079,9 +1079,51 @@ def golden_getdist(R):
     print("wrote getdist_g9.json")
 
 
+def golden_beamfuncs(R):
+    """G10: the object-level API of BeamFit/BeamModel.py, NormalizedBeamModel.py and the plane
+    helpers of OffsetNormalizedBeamModel.py (set_Cinv scalars, gauss2d / at / atxy values, package
+    round trips, planexy / plane)."""
+    import json
+    BM = R["BeamFit.BeamModel"]
+    ONB = R["BeamFit.OffsetNormalizedBeamModel"]
+    NBM = importlib.import_module("MCMC.BeamFit.NormalizedBeamModel")
+    rng = np.random.default_rng(1010)
+    x = rng.uniform(-20, 20, 40)
+    y = rng.uniform(-20, 20, 40)
+    cases = []
+    for _ in range(6):
+        center = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+        sigmas = (float(rng.uniform(3, 8)), float(rng.uniform(3, 8)))
+        angle = float(rng.uniform(-1, 4))
+        amp = float(rng.uniform(0.5, 12))
+        m = BM.GaussianBeamModel2D(center, sigmas, angle)
+        n = NBM.NormalizedBeamModel(center, sigmas, angle, amp)
+        rho = float(rng.uniform(-0.8, 0.8))
+        mxy = BM.GaussianBeamModel2D_xy(center, sigmas, rho)
+        flat5 = BM.GaussianBeamModel2D.unpackage((center, sigmas, angle))
+        cases.append(dict(
+            center=center, sigmas=sigmas, angle=angle, amp=amp, rho_in=rho,
+            angle_mod=float(m.angle), sig2_xy=[float(v) for v in m.sig2_xy], rho=float(m.rho),
+            Cinv=m.Cinv.tolist(), atxy=m.atxy(x, y).tolist(), get_XYRho_s2=[float(v) for v in m.get_XYRho()[1]],
+            flat5=flat5.tolist(), pack5=[list(BM.GaussianBeamModel2D.package(flat5)[0]),
+                                         list(BM.GaussianBeamModel2D.package(flat5)[1]),
+                                         float(BM.GaussianBeamModel2D.package(flat5)[2])],
+            norm_atxy=n.atxy(x, y).tolist(),
+            xy_sig2=[float(v) for v in mxy.sig2_xy], xy_Cinv=mxy.Cinv.tolist(), xy_atxy=mxy.atxy(x, y).tolist(),
+            xy_flat=BM.GaussianBeamModel2D_xy.unpackage((center, sigmas, rho)).tolist(),
+            planexy=np.asarray(ONB.planexy(0.93, 1.1, x, y)).tolist(),
+            plane=np.asarray(ONB.plane(0.93, 1.1, types.SimpleNamespace(x=x, y=y))).tolist()))
+    out = dict(ref_sha=ref_tree_sha(), x=x.tolist(), y=y.tolist(), cases=cases,
+               planexy_mu1=ONB.planexy(1, 0.3, 1.0, 2.0),
+               gauss2d=BM.gauss2d(x, y, 0.5, -0.25, 0.04, -0.01, 0.09).tolist())
+    with open(os.path.join(OUT, "beamfuncs_g10.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote beamfuncs_g10.json")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist", "beamfuncs"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -1095,6 +1137,8 @@ def main():
         golden_clfiles(R)
     if "getdist" in which:
         golden_getdist(R)
+    if "beamfuncs" in which:
+        golden_beamfuncs(R)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,134 @@
+"""Object-level API of mcmc_amd/BeamFit against the reference's BeamModel.py,
+NormalizedBeamModel.py and the plane helpers of OffsetNormalizedBeamModel.py
+(tests/golden/beamfuncs_g10.json, made by `oracle/make_golden.py beamfuncs` from the reference):
+host-side scalars and packaging on the CPU (no library call), beam values and the driver
+(ProcessBeamData.setup_sampler / sample1beam) on the GPU."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def g10():
+    with open(os.path.join(HERE, "golden", "beamfuncs_g10.json")) as f:
+        return json.load(f)
+
+
+def test_shape_scalars_packaging_and_plane_helpers(g10):
+    """setParameters_MajMinAng / setParameters_XYRho / set_Cinv, package / unpackage, planexy /
+    plane: bit for bit (the same operations in the same order on the host)."""
+    from mcmc_amd.BeamFit import BeamModel as BM
+    from mcmc_amd.BeamFit import NormalizedBeamModel as NBM
+    from mcmc_amd.BeamFit import OffsetNormalizedBeamModel as ONB
+    x, y = np.array(g10["x"]), np.array(g10["y"])
+    for c in g10["cases"]:
+        m = BM.GaussianBeamModel2D(tuple(c["center"]), tuple(c["sigmas"]), c["angle"])
+        assert m.angle == c["angle_mod"] and m.rho == c["rho"]
+        np.testing.assert_array_equal(m.sig2_xy, c["sig2_xy"])
+        np.testing.assert_array_equal(m.Cinv, c["Cinv"])
+        np.testing.assert_array_equal(m.get_XYRho()[1], c["get_XYRho_s2"])
+        assert m.get_MajMinAng() == (tuple(c["center"]), tuple(c["sigmas"]), c["angle_mod"])
+        flat = BM.GaussianBeamModel2D.unpackage((c["center"], c["sigmas"], c["angle"]))
+        np.testing.assert_array_equal(flat, c["flat5"])
+        pk = BM.GaussianBeamModel2D.package(flat)
+        assert [list(pk[0]), list(pk[1]), float(pk[2])] == c["pack5"]
+        mxy = BM.GaussianBeamModel2D_xy(tuple(c["center"]), tuple(c["sigmas"]), c["rho_in"])
+        np.testing.assert_array_equal(mxy.sig2_xy, c["xy_sig2"])
+        np.testing.assert_array_equal(mxy.Cinv, c["xy_Cinv"])
+        np.testing.assert_array_equal(
+            BM.GaussianBeamModel2D_xy.unpackage((c["center"], c["sigmas"], c["rho_in"])), c["xy_flat"])
+        n = NBM.NormalizedBeamModel(tuple(c["center"]), tuple(c["sigmas"]), c["angle"], c["amp"])
+        assert n.norm == c["amp"] and n.nparam == 6
+        np.testing.assert_array_equal(n.Cinv, c["Cinv"])
+        np.testing.assert_array_equal(ONB.planexy(0.93, 1.1, x, y), c["planexy"])
+        np.testing.assert_array_equal(ONB.plane(0.93, 1.1, types.SimpleNamespace(x=x, y=y)), c["plane"])
+    assert ONB.planexy(1, 0.3, 1.0, 2.0) == g10["planexy_mu1"] == 0
+    rt = NBM.NormalizedBeamModel.package(NBM.NormalizedBeamModel.unpackage(((1., 2.), (3., 4.), 4.0, 7.0)))
+    assert rt == ((1.0, 2.0), (3.0, 4.0), 4.0 % np.pi, 7.0)
+
+
+@pytest.mark.gpu
+def test_beam_values_on_the_device(g10):
+    """gauss2d / at / atxy of the three classes through mi355_beam_gauss2d, to 1e-13 (exp of the
+    reference's own exponent)."""
+    from mcmc_amd.BeamFit import BeamModel as BM
+    from mcmc_amd.BeamFit import NormalizedBeamModel as NBM
+    x, y = np.array(g10["x"]), np.array(g10["y"])
+    np.testing.assert_allclose(BM.gauss2d(x, y, 0.5, -0.25, 0.04, -0.01, 0.09), g10["gauss2d"], rtol=1e-13)
+    assert BM.gauss2d(0.5, -0.25, 0.5, -0.25, 0.04, -0.01, 0.09) == 1.0            # scalar in, scalar out
+    data = types.SimpleNamespace(x=x, y=y)
+    for c in g10["cases"]:
+        m = BM.GaussianBeamModel2D(tuple(c["center"]), tuple(c["sigmas"]), c["angle"])
+        np.testing.assert_allclose(m.atxy(x, y), c["atxy"], rtol=1e-13)
+        np.testing.assert_allclose(m(data), c["atxy"], rtol=1e-13)
+        mxy = BM.GaussianBeamModel2D_xy(tuple(c["center"]), tuple(c["sigmas"]), c["rho_in"])
+        np.testing.assert_allclose(mxy.atxy(x, y), c["xy_atxy"], rtol=1e-13)
+        n = NBM.NormalizedBeamModel(tuple(c["center"]), tuple(c["sigmas"]), c["angle"], c["amp"])
+        np.testing.assert_allclose(n.at(data), c["norm_atxy"], rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_prior_of_the_plain_classes():
+    from mcmc_amd.BeamFit import BeamModel as BM
+    G = BM.GaussianBeamModel2D
+    saved = (G.centerMin, G.centerMax, G.sigMin, G.sigMax)
+    try:
+        G.setxyRange([-20.0, 20.0])
+        G.sigMin, G.sigMax = 3, 8
+        assert G.prior((0.0, 1.0), (4.0, 5.0), 0.3) == 1
+        assert G.prior((0.0, 21.0), (4.0, 5.0), 0.3) == 0           # centre outside the box
+        assert G.prior((0.0, 1.0), (2.0, 5.0), 0.3) == 0            # below sigMin
+        assert G.prior((0.0, 1.0), (4.0, 9.0), 0.3) == 0            # above sigMax
+        X = BM.GaussianBeamModel2D_xy
+        assert X.prior((0.0, 1.0), (4.0, 5.0), 0.5) == 1
+        assert X.prior((0.0, 1.0), (4.0, 5.0), 1.5) == 0            # |rho| > 1
+    finally:
+        G.centerMin, G.centerMax, G.sigMin, G.sigMax = saved
+
+
+@pytest.mark.gpu
+def test_setup_sampler_and_sample1beam():
+    """The beam driver end to end.  setup_sampler's start point and proposal widths against a
+    NumPy restatement of ProcessBeamData.py:149-216 on the oracle's BeamData.stats (the reference
+    module itself cannot be imported - bare `import MCMC` - so this function is parity unpinned
+    beyond that restatement); sample1beam recovers the map's parameters."""
+    from oracle import refbeam as RB
+    from mcmc_amd.BeamFit import OffsetNormalizedBeamModel as ONBM
+    from mcmc_amd.BeamFit import ProcessBeamData as PBD
+    from mcmc_amd.BeamFit.BeamData import BeamData
+    mod = ONBM.OffsetNormalizedBeamModel
+    saved = (mod.centerMin, mod.centerMax, mod.sigMin, mod.sigMax, mod.paramBlocks, mod.nBlock)
+    try:
+        x, y, d, noise, truth, prior = RB.synth_beam_maps(1, n=64, seed=8)
+        data = BeamData(x, y, d[0], noise)
+        like, prop_sigmas, start = PBD.setup_sampler([data], data, useNormalizedBeam=True, verbose=False)
+        st = RB.beam_stats(RB.BeamMap(x, y, d[0], noise), sigcut=0.0)
+        sig0 = np.maximum(np.minimum([np.sqrt(st[2]), np.sqrt(st[3])], 8), 3)
+        np.testing.assert_allclose(start[0], st[:2], rtol=1e-10)
+        np.testing.assert_allclose(start[1], sig0, rtol=1e-10)
+        assert start[2] == 0 and start[4] == (0, 1, 0)
+        assert start[3] == (d[0].max() - d[0].min()) / 2
+        ctr = d[0][(abs(x - start[0][0]) < sig0[0]) & (abs(y - start[0][1]) < sig0[1])]
+        assert prop_sigmas[3] == 2 * (ctr.max() - ctr.min()) and prop_sigmas[4] == (0.3, 0, 0)
+        delx = x.max() - x.min()
+        np.testing.assert_allclose(prop_sigmas[0], (delx / 10, delx / 10))
+        assert (mod.sigMin, mod.sigMax, mod.nBlock) == (3, 8, 7)
+        assert mod.prior(*start) == 1
+        stages, ana = PBD.sample1beam(like, prop_sigmas, start, nMC=(1500, 1500), doBlock=True,
+                                      seed=11, verbose=False)
+        last = stages[-1]
+        lp = like.lnLike(mod.package(last.samples[-1]))
+        assert abs(last.lnPr[-1] - lp) <= 1e-10 * abs(lp)
+        mean = np.asarray(mod.unpackage(mod.package(ana[0])))
+        t = truth[0]
+        assert abs(mean[0] - t[0]) < 0.2 and abs(mean[1] - t[1]) < 0.2     # centre
+        assert abs(mean[5] - t[5]) < 0.5                                   # amplitude (truth 10)
+        with pytest.raises(NotImplementedError):
+            PBD.setup_sampler([data], data, useNormalizedBeam=False)
+    finally:
+        (mod.centerMin, mod.centerMax, mod.sigMin, mod.sigMax, mod.paramBlocks, mod.nBlock) = saved
