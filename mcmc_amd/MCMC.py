@@ -21,6 +21,18 @@ class ZeroPriorError(Exception):
         return repr(self.value)
 
 
+from contextlib import contextmanager
+
+
+@contextmanager
+def finishing(obj):                                                  # MCMC.py:51-56
+    """call obj.finish() on the way out (the reference wraps its progress bar in this)"""
+    try:
+        yield obj
+    finally:
+        obj.finish()
+
+
 def _device_like(like):
     if not hasattr(like, "load_into") or not hasattr(like, "problem_kind"):
         raise NotImplementedError(

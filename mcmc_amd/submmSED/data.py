@@ -144,6 +144,10 @@ def _one_column(headers, pat, what):
     return cols[0]
 
 
+def toFloat(s):                                                      # data.py:140-141
+    return float(s) if s != '' else np.nan
+
+
 def readfluxes_DLC_2014(filename="./dat/herus_phot.csv", UL25=True, getArp220=True, del157=True,
                         is_csv=None, arp220_file=None):
     """HERUS-style photometry table, data.py:143-260: `name [obsID] z f1 e1 f2 e2 ...` with header

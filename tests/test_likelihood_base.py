@@ -77,3 +77,31 @@ def test_vanishing_model_raises_zero_posterior():
     with pytest.raises(ZeroPosterior) as err:
         like([0.0])
     assert err.value.value == (0.0,)
+
+
+def test_small_public_helpers_of_the_reference_modules():
+    """convergence.gelmanrubin (ragged chains; the reference's raises NameError), MCMC.finishing,
+    data.toFloat."""
+    import numpy as np
+    from mcmc_amd import MCMC, convergence
+    from mcmc_amd.submmSED import data
+    rng = np.random.default_rng(3)
+    chains = [rng.normal(0.1 * k, 1.0 + 0.1 * k, (200 + 30 * k, 3)) for k in range(4)]
+    r = convergence.gelmanrubin(chains, burn=20, thin=2)
+    cs = [c[20::2] for c in chains]
+    w1 = np.mean([c.var(axis=0, ddof=1) for c in cs], axis=0)
+    w0 = np.mean([c.var(axis=0) for c in cs], axis=0)
+    b = np.var([c.mean(axis=0) for c in cs], axis=0, ddof=1)
+    np.testing.assert_allclose(r, np.sqrt((w0 + b) / w1), rtol=1e-14)
+    assert r.shape == (3,) and np.all(r > 0.99)
+
+    class Bar:
+        done = False
+
+        def finish(self):
+            self.done = True
+    with pytest.raises(KeyError):
+        with MCMC.finishing(Bar()) as b_:
+            raise KeyError("x")
+    assert b_.done
+    assert data.toFloat("1.5") == 1.5 and np.isnan(data.toFloat(""))
