@@ -49,3 +49,9 @@ class binnedClLikelihood(Likelihood.Likelihood):
     def lnLike(self, params):                                        # :26-32
         """params [npar] -> float; [n, npar] -> array of n log-likelihoods (one launch)."""
         return self.engine.cl_lnlike(np.asarray(params, dtype=np.float64))
+
+    def chi2(self, params):
+        """-2 lnLike: the chi-square the summaries of getdist_ahj print.  (The reference inherits
+        Likelihood.chi2, which asks each data set for a chi2() that ClData does not have, so its
+        band-power runs end in AttributeError at that print, test_binnedCl.py:244-249.)"""
+        return -2.0 * self.lnLike(params)

@@ -220,3 +220,7 @@ def FisherWindows(F, bins=None, isCovar=False):
                 WBl[ib, ispec, b[0]:b[1] + 1] = fish[ib, jb] / (b[1] - b[0]) / fish[ib, ib]
                 jb += 1
     return WBl
+
+
+class unphys(Exception):                                             # :507 (never raised there)
+    pass
