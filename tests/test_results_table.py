@@ -85,3 +85,27 @@ def test_model_selection_matches_reference_pairs():
     assert drv.select_model(True, False) == (M.submmModel1, L.SEDLikelihood1)
     assert drv.select_model(False, False) == (M.submmModel2, L.SEDLikelihood2)
     assert drv.select_model(False, True, opticallyThick=True)[0] is M.submmModel1_opticallythick_logA
+
+
+def test_readtab_reads_what_writetab_wrote(tmp_path, capsys):
+    """submmSED/readtab.readtab (readtab.py:11-23) on a table of driver.writeTab: one field per
+    column, the numbers exactly as written."""
+    from mcmc_amd.submmSED.readtab import readtab
+    recs = fake_records(5, 6, 3, 2, seed=4)
+    tab = drv.results_table(recs, 0)
+    f = str(tmp_path / "t.txt")
+    drv.writeTab(tab, f)
+    got = readtab(f)
+    out = capsys.readouterr().out
+    npar = tab["MLpar"].shape[1]
+    assert got.shape == (5,) and "z" in got.dtype.names and "ML_chi2" in got.dtype.names
+    np.testing.assert_array_equal(got["z"], tab["z"])
+    for k in range(npar):
+        np.testing.assert_array_equal(got["ML_param_%d" % k], tab["MLpar"][:, k])
+        np.testing.assert_array_equal(got["Mean_param_%d" % k], tab["mean"][:, k])
+        np.testing.assert_array_equal(got["sigma_param_%d" % k], tab["sig"][:, k])
+    np.testing.assert_array_equal(got["ML_chi2"], tab["ML_chi2"])
+    np.testing.assert_array_equal(got["flux_1"], tab["dat"][:, 1, 0])
+    np.testing.assert_array_equal(got["greybody_flux_0"], tab["flux"][:, 0])
+    assert np.all(np.isnan(got["Name"]))
+    assert "ML_chi2 = %f +- %f" % (tab["ML_chi2"].mean(), tab["ML_chi2"].std()) in out
