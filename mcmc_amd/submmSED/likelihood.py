@@ -83,6 +83,18 @@ class SEDLikelihood2(_SEDLikelihood):
     def getDerived(self, *params):
         return np.log10(self.MLamplitude) if dolog10 else self.MLamplitude
 
+    def lnLike1(self, model_vals=None, data=None):        # likelihood.py:35-74
+        """one data set, model values given ([n, 2]: the two un-normalised greybodies): the
+        quadratic forms on the device (mi355_gauss_quadform), the 2x2 solve here (the reference
+        calls scipy's solve with a keyword SciPy no longer has and raises TypeError)"""
+        FNiF = data.quadform(model_vals)
+        FNid = data.quadform(model_vals, data.d)
+        try:
+            self.MLamplitude = np.linalg.solve(FNiF, FNid)
+        except np.linalg.LinAlgError:
+            raise ZeroPosterior
+        return 0.5 * np.dot(FNid.transpose(), self.MLamplitude)
+
 
 class SEDLikelihood1(_SEDLikelihood):
     """one greybody, amplitude marginalised: lnL = 1/2 (F N^-1 d)^2 / (F N^-1 F).
@@ -93,10 +105,19 @@ class SEDLikelihood1(_SEDLikelihood):
     def getDerived(self, *params):
         return [np.log10(self.MLamplitude)] if dolog10 else [self.MLamplitude]
 
+    def lnLike1(self, model_vals=None, data=None):        # likelihood.py:99-110
+        FNiF = data.quadform(model_vals)
+        FNid = data.quadform(model_vals, data.d)
+        self.MLamplitude = FNid / FNiF
+        return 0.5 * FNid * self.MLamplitude
+
 
 class SEDLikelihood_normalized(_SEDLikelihood):
     """explicit amplitudes: lnL = -chi2/2.  likelihood.py:128-164"""
     nDerived = 0
+
+    def lnLike1(self, model_vals=None, data=None):        # likelihood.py:141-155
+        return -0.5 * data.chi2(model_vals)
 
     def lnNorm1(self, data=None):                         # likelihood.py:158-164
         return -0.5 * (data.n * np.log(2 * np.pi) + data.lnDetN)

@@ -53,6 +53,21 @@ def test_likelihood_classes_anchor_values(arp220):
     like = likelihood.SEDLikelihood1(data=arp220, model=model.submmModel1)
     like.lnLike((2, 10))
     assert like.getDerived() == [like.MLamplitude] and like.MLamplitude > 0
+    # the per-data-set protocol of the reference, like.lnLike1(model_vals, data) (Likelihood.py:70-75):
+    # model values from the model object, quadratic forms / chi2 from the data object, both on the
+    # device, against the fused-kernel lnLike of the same point
+    for mod, lk, th, val in cases:
+        like = lk(data=arp220, model=mod)
+        vals = mod(*th)(arp220)
+        got1 = like.lnLike1(vals, arp220)
+        assert abs(got1 - val) <= 1e-11 * abs(val)
+    l2 = likelihood.SEDLikelihood2(data=arp220, model=model.submmModel2)
+    th2 = (2.0, 10.0, 1.5, 30.0)
+    whole = l2.lnLike(th2)
+    amp_fused = np.array(l2.MLamplitude, dtype=float)
+    part = l2.lnLike1(model.submmModel2(*th2)(arp220), arp220)
+    assert abs(part - whole) <= 1e-8 * abs(whole)             # the nearly singular 2x2 system
+    np.testing.assert_allclose(l2.MLamplitude, amp_fused, rtol=1e-6)
 
 
 @pytest.mark.parametrize("mid", range(8))
