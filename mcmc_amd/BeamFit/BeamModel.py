@@ -81,6 +81,21 @@ class GaussianBeamModel2D(object):
         flat = np.array([center[0], center[1], sigmas[0], sigmas[1], angle, 1.0, 0.0, 1.0, 0.0])
         return int(eng.beam_prior_package(flat)[0])
 
+    def startfrom(self, data=None, random=None):                     # :205-225
+        """a random starting point inside the class-level centre box when `random` is given (the
+        reference draws it with an unimported `uniform` and drops it; here it is returned)"""
+        if random is None:
+            return None
+        dx = (self.centerMin[0], self.centerMax[0])
+        dy = (self.centerMin[1], self.centerMax[1])
+        u = np.random.uniform
+        return ((u(*dx), u(*dy)), (u(0, (dx[1] - dx[0]) / 5), u(0, (dy[1] - dy[0]) / 5)),
+                self._start_last())
+
+    @staticmethod
+    def _start_last():
+        return np.random.uniform(0, math.pi / 2)                     # the angle
+
     @classmethod
     def setsigMax(cls, xmax, ymax=None):                             # :75-86
         try:
@@ -140,6 +155,10 @@ class GaussianBeamModel2D_xy(GaussianBeamModel2D):
         if rho < -1 or rho > 1:
             return 0
         return 1
+
+    @staticmethod
+    def _start_last():
+        return np.random.uniform(-1, 1)                              # rho (:280-282)
 
     def unpackage_xy(param_seqs):                                    # :251-254
         xy, sigxy, rho = param_seqs
