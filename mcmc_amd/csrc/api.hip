@@ -357,6 +357,8 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     const double emax = std::fmax(std::fabs(3.0 + m->bmin), std::fabs(3.0 + m->bmax));
     bool ok = m->Tmin > 0.0 && std::isfinite(m->bmin) && std::isfinite(m->bmax) &&
               c->kc.hk_nub / m->Tmin < 300.0 &&
+              m->Tmax > 0.0 && c->kc.hk_nub2 / m->Tmax >= 0.5 &&   // 2^(y_b) - 1 by subtraction
+
               std::fmax(std::fabs(m->bmin), std::fabs(m->bmax)) * std::fabs(c->kc.ln_nub_hi) < 300.0;
     for (int64_t s = 0; s < S && ok; ++s)
       for (int j = 0; j < nb[s]; ++j) {

@@ -135,7 +135,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double T = th[2], e3 = 3.0 + th[1];
     const double rT = rcp_nr2(T);                          // T >= Tmin > 0 on this path
     // same base-2 form of the band term as the two-component branch below
-    const double ae = A * exp2m1_fast(k.hk_nub2 * rT);
+    const double ae = A * (exp2_tab(k.hk_nub2 * rT, B.e2t) - 1.0);   // y_b >= 0.5: fast_ok
     double chi2 = 0.0;
     for (int j = 0; j < B.nbu; ++j) {
       const double y = B.hnu2(j) * rT;
@@ -161,8 +161,13 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     // part of log2(nu/nu_b) (its rounding, |a - y| 2^-53 in the result, is the error that
     // matters; tests/parity_margin.py: lnL within 2.5e-14 of the oracle); the two components
     // share one division, (n1 d2 + n2 d1) / (d1 d2) with d in (0, 1].
-    const double ae1 = A1 * exp2m1_fast(k.hk_nub2 * rT1);
-    const double ae2 = A2 * exp2m1_fast(k.hk_nub2 * rT2);
+    // 2^(y_b) - 1 of the normalisation through the table-driven kernel: y_b >= 0.5 over the prior
+    // box is part of fast_ok, so the subtraction costs at most one bit
+    const double yb[2] = {k.hk_nub2 * rT1, k.hk_nub2 * rT2};
+    double eb[2];
+    exp2_tab_n<2>(yb, B.e2t, eb);
+    const double ae1 = A1 * (eb[0] - 1.0);
+    const double ae2 = A2 * (eb[1] - 1.0);
     double chi2 = 0.0;
     for (int j = 0; j < B.nbu; ++j) {
       const double hn = B.hnu2(j), lh = B.lhi(j);
@@ -207,7 +212,7 @@ constexpr int kIncBands = 8;            // bands per source the register cache i
 __device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands& B,
                                                const SedConsts& k, double* u) {
   const double rT = rcp_nr2(T);
-  const double em = exp2m1_fast(k.hk_nub2 * rT);
+  const double em = exp2_tab(k.hk_nub2 * rT, B.e2t) - 1.0;          // y_b >= 0.5: fast_ok
 #pragma unroll
   for (int q = 0; q < kIncBands; q += 2) {
     if (q < B.nb) {
