@@ -208,6 +208,14 @@ __device__ __forceinline__ double exp2_tab(double y, const double* tab) {
   return r;
 }
 
+// e^x of the accept test (MCMC.py:264, x = ln alpha < 0) as 2^(x log2 e) through the table: the
+// rounding of the product puts |x| 1.1e-16 on top of exp2_tab's error (x = -40: 5e-15 relative, on a
+// number that is only compared with a uniform draw); clamped so that the result stays a normal
+// number; NaN compares as "reject" like the exp it replaces.
+__device__ __forceinline__ double exp_accept(double x, const double* tab) {
+  return exp2_tab(fmax(x * kLog2e, -1000.0), tab);
+}
+
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.

@@ -270,6 +270,8 @@ __device__ __forceinline__ void gmh_tri_decode(int e, int& i, int& j) {
 // dynamic LDS: d[P][cb] doubles + accepted[cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   extern __shared__ double gmh_lds[];
+  const double* e2t = stage_exp2_table();                  // the accept test's exp, as the fused kernel
+  __syncthreads();
   const GmhLane t = gmh_lane(a);
   const int P = a.pb.P;
   const int64_t N = a.N, n = t.n;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
       if (!(lnalpha >= 0.0)) {
         const double u = a.inj_u ? a.inj_u[n]
                                  : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
-        reject = !(exp_fast(lnalpha) > u);                 // :264
+        reject = !(exp_accept(lnalpha, e2t) > u);          // :264
       }
       accepted = !reject;
     }

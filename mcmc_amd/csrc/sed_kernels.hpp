@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 #if MI355_ABL == 4
         const bool reject = !(lnalpha >= 0.0) && !(1.0 + lnalpha > u);
 #else
-        const bool reject = !(lnalpha >= 0.0) && !(exp_fast(lnalpha) > u);   // :264
+        const bool reject = !(lnalpha >= 0.0) && !(exp_accept(lnalpha, e2t) > u);   // :264
 #endif
         if (!reject) {
           accepted = true;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         const double lnalpha = v - lnPr;                   // :251
-        const bool reject = !(lnalpha >= 0.0) && !(exp_fast(lnalpha) > u);   // :264
+        const bool reject = !(lnalpha >= 0.0) && !(exp_accept(lnalpha, e2t) > u);   // :264
         if (!reject) {
           accepted = true;
           next = v;
