@@ -763,7 +763,7 @@ int mi355_gauss_quadform(mi355_ctx* c, int64_t m, int64_t n, const double* A, co
 int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* cc, double* out) {
   MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
-  MI355_REQUIRE(fn >= 0 && fn <= 10, "mi355_math_probe: unknown function %d", fn);
+  MI355_REQUIRE(fn >= 0 && fn <= 12, "mi355_math_probe: unknown function %d", fn);
   MI355_REQUIRE((fn != 2 && fn != 3) || b, "mi355_math_probe: b required");
   MI355_REQUIRE(fn != 2 || cc, "mi355_math_probe: c required");
   MI355_HIP(hipSetDevice(c->device));

@@ -216,6 +216,21 @@ __device__ __forceinline__ double exp_accept(double x, const double* tab) {
   return exp2_tab(fmax(x * kLog2e, -1000.0), tab);
 }
 
+// sqrt(x) for Box-Muller's radius, x = -2 ln u in [0, 75]: v_rsq_f64 and one coupled Goldschmidt
+// step with a residual correction (< 1 ulp; the compiler's sqrt adds range scaling, a second
+// correction and the special-case selects).  x = 0 (u rounds to 1 once in 2^53 draws) is lifted to
+// 2^-1000, whose root 2^-500 stands in for 0.
+__device__ __forceinline__ double sqrt_fast(double x) {
+  x = fmax(x, 0x1.0p-1000);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  return fma(d, h, g);
+}
+
 // a/b by Newton-Raphson on v_rcp_f64 plus one residual correction (Markstein): correctly rounded
 // in all but ~1e-3 of cases (then 1 ulp off), for b and a/b in the normal range.  No scaling /
 // fix-up for subnormal or overflowing quotients - callers keep operands away from those.

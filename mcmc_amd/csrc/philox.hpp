@@ -46,8 +46,11 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 
 __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
-  const uint64_t k = (static_cast<uint64_t>(hi) << 21) | (static_cast<uint64_t>(lo) >> 11);
-  return (static_cast<double>(k) + 0.5) * 0x1.0p-53;
+  // = (double(hi<<21 | lo>>11) + 0.5) * 2^-53 with its one rounding: the low 21 bits and the half
+  // are exact in c, the last FMA rounds the exact sum (two 32-bit conversions and two FMAs instead
+  // of a 64-bit conversion)
+  const double c = fma(static_cast<double>(lo >> 11), 0x1.0p-53, 0x1.0p-54);
+  return fma(static_cast<double>(hi), 0x1.0p-32, c);
 }
 
 __device__ __forceinline__ Philox4 philox_pair(uint64_t seed, uint32_t purpose, uint64_t chain,
@@ -71,7 +74,7 @@ __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t purpose, 
                                                uint64_t pair, double& za, double& zb) {
   double u1, u2;
   philox_uniform2(seed, purpose, chain, pair, u1, u2);
-  const double r = sqrt(-2.0 * log_fast(u1));
+  const double r = sqrt_fast(-2.0 * log_fast(u1));
   double s, c;
   sincos2pi_fast(u2, &s, &c);
   za = r * c;

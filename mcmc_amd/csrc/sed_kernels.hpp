@@ -593,6 +593,8 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
     case 8: v = pow2_prelog(a[i], b[i], c[i]); break;
     case 9: v = exp2_tab(a[i], tab); break;
     case 10: v = exp2_fast(a[i]); break;
+    case 11: v = sqrt_fast(a[i]); break;
+    case 12: v = u53(static_cast<uint32_t>(a[i]), static_cast<uint32_t>(b[i])); break;
     default: v = exp10_fast(a[i]); break;
   }
   out[i] = v;

@@ -130,3 +130,21 @@ def test_exp2_kernels_of_the_band_loop(eng):
     print("exp2_fast: max %.2f ulp" % w)
     assert w <= 1.2
     np.testing.assert_array_equal(eng.math_probe(9, np.arange(-64.0, 65.0)), 2.0 ** np.arange(-64.0, 65.0))
+
+
+def test_box_muller_radius_and_uniforms(eng):
+    """sqrt on [0, 75] (the radius sqrt(-2 ln u)) and the 53-bit uniform of two Philox words, which
+    has to be the stream definition's ((hi<<21 | lo>>11) + 0.5) 2^-53 to the bit."""
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(0, 75, 6000), 10 ** rng.uniform(-16, 0, 2000), [1.0, 2.0, 4.0, 73.47]])
+    w = ulp_err(eng.math_probe(11, x), [mp.sqrt(mp.mpf(float(v))) for v in x])
+    print("sqrt: max %.2f ulp" % w)
+    assert w <= 1.0
+    assert eng.math_probe(11, np.array([0.0]))[0] == 2.0 ** -500
+    hi = np.concatenate([rng.integers(0, 2 ** 32, 20000, dtype=np.uint64),
+                         np.array([0, 0, 2 ** 32 - 1, 2 ** 32 - 1, 2 ** 31, 2 ** 31], np.uint64)])
+    lo = np.concatenate([rng.integers(0, 2 ** 32, 20000, dtype=np.uint64),
+                         np.array([0, 2 ** 32 - 1, 0, 2 ** 32 - 1, 2 ** 11, 2 ** 11 - 1], np.uint64)])
+    want = (((hi << np.uint64(21)) | (lo >> np.uint64(11))).astype(np.float64) + 0.5) * 2.0 ** -53
+    got = eng.math_probe(12, hi.astype(np.float64), lo.astype(np.float64))
+    np.testing.assert_array_equal(got, want)
