@@ -90,12 +90,12 @@ def cpu_vectorised(seconds=4.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)   # x 200 = the 10 000 measured MH steps of SURVEY 8(d)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sources", type=int, default=100000)
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--inner", type=int, default=200, help="MH steps per chain per launch")
-    ap.add_argument("--adapt", type=int, default=400, help="untimed stage-0 steps before newMCMC")
+    ap.add_argument("--adapt", type=int, default=2000, help="untimed stage-0 steps before newMCMC (SURVEY 8(d): 2 000)")
     ap.add_argument("--ess-steps", type=int, default=2000,
                     help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
     ap.add_argument("--incremental-steps", type=int, default=3,
@@ -170,6 +170,8 @@ def main():
         kernel_ms.append(eng.last_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print("kernel ms per launch:", " ".join("%.2f" % v for v in kernel_ms), file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

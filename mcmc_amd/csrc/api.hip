@@ -24,7 +24,7 @@ static const int kModelNParam[MI355_SED_NMODEL] = {3, 3, 6, 6, 2, 4, 4, 4};
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-constexpr size_t kLdsLimit = 64 * 1024 - 512;   // dynamic LDS a block may ask for without opt-in (512 B static: the 2^y table)
+constexpr size_t kLdsLimit = 64 * 1024 - kExp2Entries * sizeof(double);   // dynamic LDS a block may ask for without opt-in (static: the 16 KB 2^y table)
 
 // LDS bytes a `bs`-chain block needs for the band tables of the sources it can touch
 static size_t lds_bytes(int bs, int C, int nbm, int64_t nsources) {

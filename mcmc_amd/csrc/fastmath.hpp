@@ -134,39 +134,26 @@ __device__ __forceinline__ double exp2_fast(double y) {
 }
 
 // ---- table-driven 2^y (the band loop of the SED fast path) ------------------------------------
-// y = k/64 + f with k = round(64 y) taken from the low mantissa bits of y + 1.5 2^46 (no v_rndne /
-// v_cvt), |f| <= 1/128:  2^y = 2^(k >> 6) * T[k & 63] * (1 + f P(f)),  T[i] = 2^(i/64) correctly
-// rounded (64 doubles in LDS), P the degree-4 Taylor polynomial of (2^f - 1)/f (remainder
-// (f ln 2)^6/6! < 4e-17), and the power of two added to the exponent field (results stay normal:
-// callers bound |y| < 1000).  13 instructions against the 16 of exp2_fast's degree-11 chain - on
-// this kernel every VALU instruction costs one issue slot whatever its type
+// y = k/2048 + f with k = round(2048 y) taken from the low mantissa bits of y + 1.5 2^41 (no
+// v_rndne / v_cvt), |f| <= 2^-12:  2^y = 2^(k >> 11) * T[k & 2047] * (1 + f P(f)),  T[i] = 2^(i/2048)
+// correctly rounded (16 KB in LDS, exp2_table.inc from tools/gen_exp2_table.py), P the degree-2
+// Taylor polynomial of (2^f - 1)/f (remainder (f ln 2)^4/4! < 4e-17), and the power of two added
+// to the exponent field (results stay normal: callers bound |y| < 1000).  11 instructions against
+// the 16 of exp2_fast's degree-11 chain (13 with a 64-entry table and a degree-4 P) - on this
+// kernel every VALU instruction costs one issue slot whatever its type
 // (profiles/r1_bench_summary.txt), so the count is what matters; error <= 1.3 ulp
 // (tests/test_fastmath_gpu.py).
-constexpr int kExp2Bits = 6;
+constexpr int kExp2Bits = 11;
 constexpr int kExp2Entries = 1 << kExp2Bits;
 static __device__ const double kExp2Table[kExp2Entries] = {
-    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+#include "exp2_table.inc"
+};
 
 // The block's copy of the table in LDS.  Every thread of the block must call this before the
 // block's next __syncthreads(); the pointer is valid after that barrier.
 __device__ __forceinline__ const double* stage_exp2_table() {
   __shared__ double tab[kExp2Entries];
-  if (threadIdx.x < kExp2Entries) tab[threadIdx.x] = kExp2Table[threadIdx.x];
+  for (int i = threadIdx.x; i < kExp2Entries; i += blockDim.x) tab[i] = kExp2Table[i];
   return tab;
 }
 
@@ -176,22 +163,18 @@ __device__ __forceinline__ const double* stage_exp2_table() {
 // waves per SIMD nothing else hides them.
 template <int N>
 __device__ __forceinline__ void exp2_tab_n(const double* y, const double* tab, double* out) {
-  constexpr double kMagic = 0x1.8p52 / kExp2Entries;      // ulp = 1/64
+  constexpr double kMagic = 0x1.8p52 / kExp2Entries;      // ulp = 1/2048
   int k[N];
   double f[N], T[N], p[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double t = y[i] + kMagic;
-    k[i] = __double2loint(t);                             // round(64 y), two's complement
+    k[i] = __double2loint(t);                             // round(2048 y), two's complement
     f[i] = y[i] - (t - kMagic);                           // exact
     T[i] = tab[k[i] & (kExp2Entries - 1)];
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) p[i] = fma(0x1.5d87fe78a6731p-10, f[i], 0x1.3b2ab6fba4e77p-7);
-#pragma unroll
-  for (int i = 0; i < N; ++i) p[i] = fma(p[i], f[i], 0x1.c6b08d704a0c0p-5);
-#pragma unroll
-  for (int i = 0; i < N; ++i) p[i] = fma(p[i], f[i], 0x1.ebfbdff82c58fp-3);
+  for (int i = 0; i < N; ++i) p[i] = fma(0x1.c6b08d704a0c0p-5, f[i], 0x1.ebfbdff82c58fp-3);
 #pragma unroll
   for (int i = 0; i < N; ++i) p[i] = fma(p[i], f[i], 0x1.62e42fefa39efp-1);
 #pragma unroll

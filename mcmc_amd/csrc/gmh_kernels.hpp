@@ -270,8 +270,8 @@ __device__ __forceinline__ void gmh_tri_decode(int e, int& i, int& j) {
 // dynamic LDS: d[P][cb] doubles + accepted[cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   extern __shared__ double gmh_lds[];
-  const double* e2t = stage_exp2_table();                  // the accept test's exp, as the fused kernel
-  __syncthreads();
+  const double* e2t = kExp2Table;   // the accept test's exp as in the fused kernels; one lane per chain
+                                    // uses it once, so the table is read where it lies (no LDS copy)
   const GmhLane t = gmh_lane(a);
   const int P = a.pb.P;
   const int64_t N = a.N, n = t.n;
