@@ -114,7 +114,7 @@ def test_box_muller_kernels(eng):
 
 def test_exp2_kernels_of_the_band_loop(eng):
     """2^y as the SED band loop and the beam pixel loop evaluate it: the table-driven kernel
-    (exp2_tab: 64-entry table, degree-4 polynomial, integer exponent arithmetic) and the plain
+    (exp2_tab: 2048-entry table, degree-2 polynomial, integer exponent arithmetic) and the plain
     degree-11 chain (exp2_fast), on the whole range the fast path admits, at the table's grid
     points k/64 and next to the rounding boundaries (k + 1/2)/64."""
     rng = np.random.default_rng(9)
