@@ -171,7 +171,11 @@ __device__ __forceinline__ void exp2_tab_n(const double* y, const double* tab, d
     const double t = y[i] + kMagic;
     k[i] = __double2loint(t);                             // round(2048 y), two's complement
     f[i] = y[i] - (t - kMagic);                           // exact
-    T[i] = tab[k[i] & (kExp2Entries - 1)];
+    // byte offset of the entry: shift and mask, two instructions (the compiler's own lowering of
+    // tab[k & 2047] for several k at once packs halves with v_perm / v_bitop3 and takes more)
+    int off;
+    asm("v_lshlrev_b32 %0, 3, %1\n\tv_and_b32 %0, 0x3ff8, %0" : "=v"(off) : "v"(k[i]));
+    T[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + off);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) p[i] = fma(0x1.c6b08d704a0c0p-5, f[i], 0x1.ebfbdff82c58fp-3);
@@ -180,8 +184,7 @@ __device__ __forceinline__ void exp2_tab_n(const double* y, const double* tab, d
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double r = fma(T[i] * f[i], p[i], T[i]);        // T (1 + f P(f)), in [1, 2)
-    const int hi = __double2hiint(r) + ((k[i] >> kExp2Bits) << 20);
-    out[i] = __hiloint2double(hi, __double2loint(r));
+    out[i] = ldexp(r, k[i] >> kExp2Bits);                 // v_ashrrev + v_ldexp_f64
   }
 }
 
