@@ -268,8 +268,10 @@ class MCMC(object):
             start = np.asarray(self.mean(burn, stride), np.float64)
             std = np.asarray(self.stdev(burn, stride), np.float64)
             if random:
-                z, _ = eng.rng_dump(eng.step_total, 1, self.nchains, npar)
-                start = start + z[0].reshape(start.shape) * std
+                # host-side restart offsets from a generator of their own, keyed by (seed, stage):
+                # the device's normal stream at step_total is what the next MC_append consumes
+                rng = np.random.default_rng([self.seed & 0xFFFFFFFFFFFFFFFF, int(eng.stage), 0x5EED])
+                start = start + rng.standard_normal(start.shape) * std
             sig = np.array([self.like.model.package(f * s) for s in np.atleast_2d(std)])
             blocks = np.asarray(self.like.model.paramBlocks, dtype=np.int32) if doBlock else None
             self._reinit(eng, np.atleast_2d(start)[None], sig[None], blocks, True)

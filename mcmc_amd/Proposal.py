@@ -4,6 +4,8 @@ In this implementation the draws happen inside the MH kernel (Philox4x32-10 + Bo
 proposal object is the host-side description of the density - widths, optional Cholesky factor
 of the normalised covariance, rotation flag - that MCMC hands to the device.  getNewParams is
 kept for API compatibility and is itself served by the device generator."""
+import os
+
 import numpy as np
 
 
@@ -26,7 +28,9 @@ def GenericGaussianProposal(package=None, unpackage=None):
                 else:
                     self.setNormalizedMatrixFromSqrt(matrix)
             self.rotateParams = rotateParams
-            self._draws = 0
+            # the reference reseeds from OS entropy per instance (Proposal.py:64): every instance
+            # gets its own window of the device generator's stream
+            self._draws = int.from_bytes(os.urandom(4), "little") << 20
 
         def setSigmas(self, sigmas):                      # Proposal.py:114-117
             self.sigmas = np.asarray(self.unpackage(sigmas), dtype=np.float64)

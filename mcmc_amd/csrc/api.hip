@@ -863,6 +863,7 @@ int mi355_mh_ess(mi355_ctx* c, double* ess) {
 
 int mi355_rhat(mi355_ctx* c, double* rhat) {
   MI355_REQUIRE(c && c->mh_ready && rhat, "mi355_rhat: bad argument");
+  MI355_HIP(hipSetDevice(c->device));
   const int64_t n = c->mhS * c->mhP;
   if (c->scratch_a.alloc(static_cast<size_t>(n) * 4)) return -2;
   double* gmean = c->scratch_a.p;
@@ -872,6 +873,7 @@ int mi355_rhat(mi355_ctx* c, double* rhat) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_scale, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, c->stream,
                      n, 1.0 / static_cast<double>(c->C), gmean);
+  MI355_HIP(hipGetLastError());
   rc = mi355_rhat_partial_async(c, 1, gmean, sums);
   if (rc) return rc;
   rc = mi355_rhat_finish_async(c, sums, c->C, out);

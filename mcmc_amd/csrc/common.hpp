@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -32,6 +33,11 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// Bumped whenever a DevBuf that held memory lets go of it (growth or release): a captured hipGraph
+// has the old addresses baked into its kernel arguments, so whoever replays one compares the
+// epoch it was captured at with the current one and recaptures when they differ (gmh_api.hip).
+inline std::atomic<uint64_t> g_devbuf_epoch{0};
+
 // Owning device buffer; freed with the context.
 template <typename T>
 struct DevBuf {
@@ -52,7 +58,10 @@ struct DevBuf {
     return 0;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      g_devbuf_epoch.fetch_add(1, std::memory_order_relaxed);
+    }
     p = nullptr;
     n = 0;
   }

@@ -26,6 +26,9 @@ struct GmhState {
   hipGraphExec_t graph_exec = nullptr;
   int graph_steps = 0;              // MH steps per graph launch
   uint64_t graph_version = 0;       // version the graph was captured for
+  uint64_t graph_epoch = 0;         // g_devbuf_epoch at capture: any buffer freed since then may
+                                    // be one the graph's kernels point at (Cl / beam scratch grows
+                                    // when a host call evaluates a batch larger than N)
   uint64_t version = 1;             // bumped whenever launch arguments may change
   ~GmhState() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -154,7 +157,9 @@ static int launch_step(mi355_ctx* c, const GmhArgs& a) {
 // one step directly since the last (re)initialisation, so every scratch buffer has its final size.
 static int build_graph(mi355_ctx* c) {
   GmhState* g = c->gmh;
-  if (g->graph_exec && g->graph_version == g->version) return 0;
+  if (g->graph_exec && g->graph_version == g->version &&
+      g->graph_epoch == g_devbuf_epoch.load(std::memory_order_relaxed))
+    return 0;
   if (g->graph_exec) { (void)hipGraphExecDestroy(g->graph_exec); g->graph_exec = nullptr; }
   if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
   if (g->dyn.alloc(2)) return -2;
@@ -189,6 +194,7 @@ static int build_graph(mi355_ctx* c) {
   }
   g->graph_steps = kGraphSteps;
   g->graph_version = g->version;
+  g->graph_epoch = g_devbuf_epoch.load(std::memory_order_relaxed);
   return 0;
 }
 

@@ -183,6 +183,10 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     return -0.5 * chi2;
   } else if constexpr (MODEL == MI355_SED_M1) {
     const double T = th[1], e3 = 3.0 + th[0];
+    // This model's prior has no upper temperature limit (model.py:244-255) while fast_ok bounds
+    // h nu/kT from below with Tmax: beyond it 1 - 2^-y loses log2(T/Tmax) more bits, so those
+    // (rare, Rayleigh-Jeans) points take the exact path.
+    if (T > k.Tmax) return sed_lnlike<MODEL>(th, B, k, derived);
     const double pre = k.prefac * pow2_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
     const double rT = 1.0 / T;
     double FNiF = 0.0, FNid = 0.0;

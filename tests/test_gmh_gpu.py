@@ -292,3 +292,39 @@ def test_loading_data_ends_the_running_sampler():
         eng.mh_init_problem("cl", 32, truth, np.full(model.nparam, 0.02), randomize_start=False)
         eng.mh_run(64)
         assert np.all(np.isfinite(eng.mh_moments()["lnPr"]))
+
+
+@pytest.mark.parametrize("kind", ["cl", "beam"])
+def test_graph_replay_survives_scratch_regrowth(kind):
+    """A host-side likelihood call on a batch much larger than the sampler's N chains regrows the
+    Cl / beam scratch buffers whose addresses a captured graph has baked in: the next long run must
+    recapture (not replay freed memory) and still equal direct launches bit for bit."""
+    from oracle import refbeam as RB
+    from oracle import refcl as RC
+    from mcmc_amd import Engine
+    rng = np.random.default_rng(4)
+    res = []
+    for traced in (False, True):
+        with Engine(seed=77) as eng:
+            if kind == "cl":
+                model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.0, lmax=700, seed=5)
+                eng.cl_load([d])
+                eng.cl_set_binning(model.bins, model.shapefun)
+                eng.mh_init_problem("cl", 1, truth, np.full(6, 0.03), param_blocks=np.arange(6))
+                big = truth[None, :] * rng.uniform(0.9, 1.1, (3000, 6))
+            else:
+                x, y, dm, noise, tr, prior = RB.synth_beam_maps(2, n=32, seed=2)
+                eng.beam_load(x, y, dm, noise, center_min=prior.center_min, center_max=prior.center_max,
+                              sig_min=prior.sig_min, sig_max=prior.sig_max)
+                sg = np.array([0.05, 0.05, 0.05, 0.05, 0.02, 0.1, 0.002, 0, 0])
+                eng.mh_init_problem("beam", 2, tr[:, None, :].repeat(2, 1), sg, param_blocks=np.arange(7))
+                big = tr[:, None, :].repeat(600, 1) * (1 + 0.01 * rng.standard_normal((2, 600, 9)))
+                big[..., 7] = 1.0
+            eng.mh_run(64, thin=1 if traced else 0)
+            before = eng.cl_lnlike(big) if kind == "cl" else eng.beam_lnlike(big)
+            eng.mh_run(64, thin=1 if traced else 0)
+            after = eng.cl_lnlike(big) if kind == "cl" else eng.beam_lnlike(big)
+            assert np.array_equal(before, after)
+            res.append(eng.mh_moments())
+    for key in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
+        assert np.array_equal(res[0][key], res[1][key]), key

@@ -99,6 +99,22 @@ def test_lnlike_matches_oracle_batch(eng, mid, C):
     print("model %d C=%d: max rel err %.2e" % (mid, C, worst))
 
 
+def test_marginalised_model_far_above_tmax(eng):
+    """submmModel1's prior has no upper temperature limit (model.py:244-255): points at T >> Tmax,
+    where 1 - 2^-y of the fast path would lose bits, take the exact path and stay at 1e-12."""
+    S, C = 40, 16
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=21)
+    nb = np.full(S, 8, np.int32)
+    eng.sed_load(R.M1, nb, nu, d, sig)
+    rng = np.random.default_rng(3)
+    th = np.stack([rng.uniform(0.5, 2.5, (S, C)), 10.0 ** rng.uniform(1.0, 7.5, (S, C))], axis=-1)
+    got = eng.sed_lnlike(th)
+    ref = np.array([[R.sed_lnlike(R.M1, th[s, c], R.GaussData(nu[s], d[s], sig[s])) for c in range(C)]
+                    for s in range(S)])
+    assert (th[..., 1] > 100.0).sum() > S * C // 2
+    assert_lnl_close(got, ref, RTOL_LNL, "M1 at large T")
+
+
 def test_empty_and_single_band_sources(eng):
     """nb=0 (no data: lnL = -0) and nb=1 sources next to a full one."""
     nu, d, sig, truth = R.synth_sed_catalogue(3, seed=3)
