@@ -315,6 +315,15 @@ int mi355_mh_init_problem(mi355_ctx* ctx, int32_t problem, int32_t C, const doub
                           int32_t theta0_per_chain, const double* sigma, int32_t sigma_per_chain,
                           const int32_t* param_blocks, int32_t nblock, int32_t randomize_start,
                           int32_t track_cov);
+/* One-launch runs for problems started with mi355_mh_init_problem.  A binnedCl problem whose data
+ * sets need at most 11 marginalisation points per chain (no marginalisation, analytic, or the
+ * 11-point calibration or beam grid) runs mi355_mh_run as ONE kernel launch: every MH step of
+ * MCMC.py:225-286 - proposal of any mode, band powers, MFMA quadratic form, marginalisation,
+ * accept, moments - inside it, chain state in LDS.  Same draws, same arithmetic, same chains as
+ * the step-wise launches, bit for bit.  on=0 forces the step-wise launches (on by default).
+ * mi355_mh_fused_active: 1 if the next mi355_mh_run of this context takes the one-launch path. */
+int mi355_mh_set_fused(mi355_ctx* ctx, int32_t on);
+int mi355_mh_fused_active(mi355_ctx* ctx);
 /* prop.setNormalizedMatrixFromSqrt(L) + prop.rotateParams = rotate (Proposal.py:106-109, :78):
  * L host [P,P] (per_chain=0) or [S,C,P,P] (=1); NULL returns to uncorrelated proposals. */
 int mi355_mh_set_sqrt_matrix(mi355_ctx* ctx, const double* L, int32_t per_chain, int32_t rotate);

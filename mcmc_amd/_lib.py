@@ -4,7 +4,9 @@ There is no CPU fallback: if the shared library is missing, or no MI355X is visi
 context is created, the caller gets an exception - never a silently different code path.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355MCMC_LIB") or os.path.join(_HERE, "libmi355mcmc.so")
@@ -105,6 +107,8 @@ SIGNATURES = {
     "mi355_mh_init_problem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32,
                                         c_double_p, C.c_int32, c_int32_p, C.c_int32, C.c_int32,
                                         C.c_int32]),
+    "mi355_mh_set_fused": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mi355_mh_fused_active": (C.c_int, [C.c_void_p]),
     "mi355_mh_set_sqrt_matrix": (C.c_int, [C.c_void_p, c_double_p, C.c_int32, C.c_int32]),
     "mi355_mh_adapt_corr": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32]),
@@ -125,11 +129,33 @@ class Mi355Error(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  A process must run on ONE HIP runtime:
+    if this library pulls in /opt/rocm's copy first, a later `import torch` binds to it and finds
+    no GPU.  So when torch is installed but not imported yet, its runtime is loaded first (the
+    order every `import torch; import mcmc_amd` program has anyway)."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library (once) and bind every declared symbol."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise Mi355Error(
             "libmi355mcmc.so not found at %s: build it with `make -C mcmc_amd/csrc` "

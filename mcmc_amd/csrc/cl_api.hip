@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "cl_kernels.hpp"
+#include "cl_mh_kernels.hpp"
 #include "problems.hpp"
 
 namespace mi355 {
@@ -28,6 +29,11 @@ struct ClProblem {
   double margenorm = 0.0;
   // per-call scratch
   DevBuf<double> q_host_layout, q_pm, bp, form, lnl, tmp_in, tmp_out;
+  // fused Metropolis-Hastings kernel (cl_mh_kernels.hpp), planned by mi355_cl_set_binning
+  int mh_nw = 0;                   // waves per block; 0: the problem needs the step-wise engine
+  int mh_nbp_max = 0, mh_fout = 9, mh_tile_doubles = 0;
+  ClMhData mh[kClMhMaxData] = {};
+  DevBuf<ClMhArgs> mh_args;        // the kernel reads its arguments from device memory
 };
 
 void cl_destroy(ClProblem* p) { delete p; }
@@ -149,6 +155,7 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   a.bfac = d->bfac.p;
   a.ninv = d->ninv.p;
   a.nsym = d->nsym.p;
+  a.nstride = d->nbp;
   a.var = d->var.p;
   a.has_x = d->has_x ? 1 : 0;
   a.beam_uncertain = d->beam_uncertain ? 1 : 0;
@@ -158,6 +165,8 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   a.nbeam = nbeam;
   a.rows = n * rows_per_chain;
   a.out = out;
+  MI355_REQUIRE(a.rows < (int64_t{1} << 31), "too many rows (%lld) for one Cl launch",
+                static_cast<long long>(a.rows));
   if (!d->has_corr) {
     const int64_t work = (mode == CL_ROWS_TRIPLE) ? n : a.rows;
     hipLaunchKernelGGL(k_cl_form_diag, dim3(static_cast<unsigned>(ceil_div64(work, 256))), dim3(256),
@@ -240,6 +249,161 @@ static int to_bandmajor(mi355_ctx* c, const double* host, int64_t n, int cols, i
   hipLaunchKernelGGL(k_cl_to_bandmajor, dim3(static_cast<unsigned>(ceil_div64(no, 256))), dim3(256),
                      0, c->stream, n, cols, colsp, stage.p, out.p);
   MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- fused Metropolis-Hastings kernel ---------------------------------------------------------
+// Waves per block of the form kernel launch_form_cg picks for a data set with nbp padded bands:
+// the fused kernel must run the same instantiation to produce the same bits.
+static int form_nw(int nbp) { return (nbp >> 4) <= 4 ? 4 : 8; }
+
+static void plan_fused(ClProblem* p) {
+  p->mh_nw = 0;
+  if (p->data.empty() || p->data.size() > static_cast<size_t>(kClMhMaxData)) return;
+  int nw = 0, nbp_max = 0, fout = 9;
+  for (size_t i = 0; i < p->data.size(); ++i) {
+    ClData* d = p->data[i].get();
+    const FormPlan f = plan_for(d);
+    if (f.rows_per_chain > kClGrid) return;        // 121 points per chain: the batched kernels win
+    if (d->has_corr) {
+      if (nw && nw != form_nw(d->nbp)) return;     // one block size serves every data set
+      nw = form_nw(d->nbp);
+    }
+    if (d->nbp > nbp_max) nbp_max = d->nbp;
+    if (f.rows_per_chain > fout) fout = f.rows_per_chain;
+    ClMhData& m = p->mh[i];
+    m = ClMhData{};
+    m.f.nb = d->nb;
+    m.f.nbp = d->nbp;
+    m.f.obs = d->obs.p;
+    m.f.xf = d->xf.p;
+    m.f.hasx = d->hasx.p;
+    m.f.beam_err = d->beam_err.p;
+    m.f.bfac = d->bfac.p;
+    m.f.ninv = d->ninv.p;
+    m.f.nsym = d->nsym.p;
+    m.f.nstride = d->nbp;
+    m.f.var = d->var.p;
+    m.f.has_x = d->has_x ? 1 : 0;
+    m.f.beam_uncertain = d->beam_uncertain ? 1 : 0;
+    m.f.calib = d->calib;
+    m.f.mode = f.mode;
+    m.f.ncal = f.ncal;
+    m.f.nbeam = f.nbeam;
+    m.K = d->K.p;
+    m.bp0 = d->bp0.p;
+    m.has_corr = d->has_corr ? 1 : 0;
+    m.rows_per_chain = f.rows_per_chain;
+    m.sym = (d->has_corr && f.mode != CL_ROWS_TRIPLE && (d->nbp >> 4) >= 8) ? 1 : 0;
+  }
+  if (!nw) nw = 4;
+  p->mh_nbp_max = nbp_max;
+  p->mh_fout = fout;
+  p->mh_tile_doubles = static_cast<int>((form_lds_bytes(nbp_max, 16, nw) + 7) / 8);
+  p->mh_nw = nw;
+}
+
+// Plan of a fused run: LDS bytes and whether the data set lives in LDS for the launch.  Resident
+// pays when the grid is at most one block per CU (6.9 against 8.9 us per step at 4096 chains,
+// nb = 64); beyond that the streamed kernel wins because two of its blocks share a CU and hide
+// one another's latencies (5.2 us per 4096 chains at 65536 chains).
+struct ClMhLds {
+  size_t bytes;
+  int resident, sb;
+};
+static ClMhLds cl_mh_plan_lds(const ClProblem* p, int P, int nblock, int npn, int64_t N) {
+  const int sb = cl_mh_cache_steps(64 * p->mh_nw, npn);
+  ClMhLds r{0, 0, sb};
+  constexpr int kCUs = 256;
+  if (p->data.size() == 1 && ceil_div64(N, kClMhChains) <= kCUs) {
+    const size_t res = cl_mh_resident_doubles(P, p->mh[0].f.nbp, p->mh[0].has_corr);
+    r.bytes = cl_mh_lds_doubles(P, nblock, npn, sb, p->mh_nbp_max, p->mh_fout, p->mh_tile_doubles, res) * 8;
+    if (r.bytes <= kClLdsBudget) {
+      r.resident = 1;
+      return r;
+    }
+  }
+  r.bytes = cl_mh_lds_doubles(P, nblock, npn, sb, p->mh_nbp_max, p->mh_fout, p->mh_tile_doubles, 0) * 8;
+  return r;
+}
+
+int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn) {
+  if (!c || !c->cl || !c->cl->binned || !c->cl->mh_nw) return 0;
+  if (P > kClMhSlots * (64 * c->cl->mh_nw / kClMhChains)) return 0;   // parameters per thread in registers
+  return cl_mh_plan_lds(c->cl, P, nblock, npn, 1 << 30).bytes <= kClLdsBudget ? c->cl->mh_nw : 0;
+}
+
+template <int NW, int FORM, bool RES>
+static int launch_cl_mh(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
+  static size_t opted[kMaxDevices] = {};
+  size_t& have = opted[c->device % kMaxDevices];
+  if (lds > 48 * 1024 && lds > have) {
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_mh_run<NW, FORM, RES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    have = lds;
+  }
+  ClProblem* p = c->cl;
+  if (p->mh_args.alloc(1)) return -2;
+  // synchronous copy from this stack frame; the stream is idle here (mi355_mh_run is synchronous)
+  MI355_HIP(hipMemcpyAsync(p->mh_args.p, &a, sizeof(ClMhArgs), hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  const unsigned grid = static_cast<unsigned>(ceil_div64(a.g.N, kClMhChains));
+  hipLaunchKernelGGL((k_cl_mh_run<NW, FORM, RES>), dim3(grid), dim3(64 * NW), lds, c->stream,
+                     static_cast<const ClMhArgs*>(p->mh_args.p));
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+// One data set: kernels compiled for its form, with its matrices in LDS (resident) or streamed
+// from L2; several data sets: the generic kernel.
+template <int NW>
+static int launch_cl_mh_form(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
+  if (a.ndata != 1) return launch_cl_mh<NW, CLMH_ANY, false>(c, a, lds);
+  const bool res = a.resident != 0;
+  switch (cl_mh_form_kind(a.data[0])) {
+    case CLMH_DIAG:
+      return res ? launch_cl_mh<NW, CLMH_DIAG, true>(c, a, lds) : launch_cl_mh<NW, CLMH_DIAG, false>(c, a, lds);
+    case CLMH_TRIPLE:
+      return res ? launch_cl_mh<NW, CLMH_TRIPLE, true>(c, a, lds)
+                 : launch_cl_mh<NW, CLMH_TRIPLE, false>(c, a, lds);
+    case CLMH_SYM:
+      if constexpr (NW == 8)                               // from 8 column tiles up
+        return res ? launch_cl_mh<8, CLMH_SYM, true>(c, a, lds) : launch_cl_mh<8, CLMH_SYM, false>(c, a, lds);
+      else
+        break;
+    default:
+      return res ? launch_cl_mh<NW, CLMH_MARGE, true>(c, a, lds)
+                 : launch_cl_mh<NW, CLMH_MARGE, false>(c, a, lds);
+  }
+  set_error("cl_mh_run: symmetrised form with a 4-wave block");
+  return -1;
+}
+
+int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t nkeep) {
+  ClProblem* p = c->cl;
+  const int nw = cl_mh_fused_nw(c, g.pb.P, g.nblock, g.npn);
+  MI355_REQUIRE(nw > 0, "cl_mh_run: the loaded Cl problem has no fused kernel");
+  const ClMhLds plan = cl_mh_plan_lds(p, g.pb.P, g.nblock, g.npn, g.N);
+  ClMhArgs a{};
+  a.g = g;
+  a.ndata = static_cast<int>(p->data.size());
+  for (int i = 0; i < a.ndata; ++i) a.data[i] = p->mh[i];
+  a.nbp_max = p->mh_nbp_max;
+  a.fout_per_chain = p->mh_fout;
+  a.tile_doubles = p->mh_tile_doubles;
+  a.resident = plan.resident;
+  a.sb = plan.sb;
+  a.weights = p->weights.p;
+  a.margenorm = p->margenorm;
+  a.nsteps = nsteps;
+  a.thin = thin;
+  a.nkeep = nkeep;
+  const size_t lds = plan.bytes;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
+  const int rc = nw == 4 ? launch_cl_mh_form<4>(c, a, lds) : launch_cl_mh_form<8>(c, a, lds);
+  if (rc) return rc;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+  if (!c->capturing) c->ev_valid = true;
   return 0;
 }
 
@@ -369,6 +533,8 @@ int mi355_cl_set_binning(mi355_ctx* c, int32_t nCl, const int32_t* nbins, const 
   }
   MI355_REQUIRE(seen_max == lmax, "lmax=%d but the largest binned multipole is %d: pass "
                 "shapefun[:, :lmax+1] for that lmax", lmax, seen_max);
+  MI355_REQUIRE(ib <= 384, "%d bins: the band-power kernel stages at most 384 bin amplitudes per "
+                "chain in LDS", ib);
   p->nCl = nCl;
   p->npar = ib;
   p->lmax = lmax;
@@ -379,6 +545,7 @@ int mi355_cl_set_binning(mi355_ctx* c, int32_t nCl, const int32_t* nbins, const 
     if (build_K(c, d.get())) return -2;
   MI355_HIP(hipStreamSynchronize(c->stream));
   p->binned = true;
+  plan_fused(p);
   return 0;
 }
 
@@ -392,9 +559,9 @@ int mi355_cl_lnlike_dev_async(mi355_ctx* c, int64_t n, const double* q_dev, doub
   int first = 1;
   for (auto& d : p->data) {
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
-    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 256)), d->nbp),
-                       dim3(256), 0, c->stream, n, p->npar, d->nb, d->nbp, q_dev, d->K.p, d->bp0.p,
-                       p->bp.p);
+    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
+                       static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
+                       d->nbp, q_dev, d->K.p, d->bp0.p, p->bp.p);
     MI355_HIP(hipGetLastError());
     int rc = dataset_from_bp(c, d.get(), p->bp.p, n, lnL_dev, first ? 0 : 1, nullptr);
     if (rc) return rc;
@@ -486,9 +653,9 @@ int mi355_cl_bandpowers(mi355_ctx* c, int32_t idata, int32_t what, int64_t n, co
   if (what == 0) {
     if (to_bandmajor(c, in, n, p->npar, p->npar, p->q_host_layout, p->q_pm)) return -2;
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
-    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 256)), d->nbp),
-                       dim3(256), 0, c->stream, n, p->npar, d->nb, d->nbp, p->q_pm.p, d->K.p,
-                       d->bp0.p, p->bp.p);
+    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
+                       static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
+                       d->nbp, p->q_pm.p, d->K.p, d->bp0.p, p->bp.p);
     MI355_HIP(hipGetLastError());
   } else {
     int rc = bp_from_cl(c, d, n, in, rows, L);

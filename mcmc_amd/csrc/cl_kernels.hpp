@@ -44,6 +44,7 @@ struct ClFormArgs {
   const double* ninv;      // [nbp][nbp] zero padded (full covariance) ...
   const double* nsym;      // [nbp][nbp] block-upper symmetrised copy: tile (I,J), I<J, holds
                            // N_IJ + N_JI^T, diagonal tiles N_II, tiles I>J unused (k_cl_form SYM)
+  int nstride;             // row stride of ninv / nsym in doubles (nbp, or padded for an LDS copy)
   const double* var;       // ... or [nbp] variances (uncorrelated errors)
   int has_x;               // dataset has_xfactors
   int beam_uncertain;
@@ -59,9 +60,10 @@ struct ClFormArgs {
 __device__ __forceinline__ void cl_row_decode(const ClFormArgs& a, int64_t grow, int& c, int& sub) {
   if (grow >= a.rows) { c = -1; sub = 0; return; }
   const int per = (a.mode == CL_ROWS_TRIPLE) ? 3 : (a.mode == CL_ROWS_RAW ? 1 : a.ncal * a.nbeam);
-  const int64_t cc = grow / per;
-  c = static_cast<int>(cc);
-  sub = static_cast<int>(grow - cc * per);
+  const int r32 = static_cast<int>(grow);                  // rows < 2^31 (run_form checks)
+  if (per == 1) { c = r32; sub = 0; return; }              // no 64-bit (or any) division on the hot path
+  c = r32 / per;
+  sub = r32 - c * per;
 }
 
 // Value of element `k` (band) of the row (c, sub): the vector the quadratic form is taken of.
@@ -111,20 +113,23 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 #ifndef MI355_CL_ABL
 #define MI355_CL_ABL 0     // timing ablations (never set in the product build)
 #endif
+// The whole tile computation is a device function so that the fused Metropolis-Hastings kernel
+// (cl_mh_kernels.hpp) runs the very same code on row tiles it generates itself: `a.bp` / `a.out`
+// may then point into LDS (a.n = chains of the block), `row0` is the tile's first row and `smem`
+// the tile's LDS region (form_lds_bytes in cl_api.hip).  All 64*NW threads of the block must call
+// it; it ends without a barrier (the caller synchronises before it touches `smem` again).
 template <int RT, int CG, int MODE, int NW, bool SYM>
-__global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
+__device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t row0, double* smem) {
   static_assert(!SYM || (CG == 1 && MODE != CL_ROWS_TRIPLE), "SYM needs CG == 1 and a diagonal form");
   constexpr int TR = 16 * RT;
   constexpr int NTHR = 64 * NW;
   constexpr int NT = (MODE == CL_ROWS_TRIPLE) ? 3 : 1;
-  extern __shared__ double smem[];
   double* vt = smem;                                       // [nbp][TR]
   double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [NW][TR][3]
   int* rowc = reinterpret_cast<int*>(red + (NW * 3 > 16 ? NW * 3 : 16) * TR);   // [TR] chain of each row
   int* rows = rowc + TR;                                   // [TR] sub-index of each row
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * rows_used;
 
   if (tid < TR) {
     int c = -1, sub = 0;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
-  const size_t kstride = static_cast<size_t>(4) * a.nbp;
+  const size_t kstride = static_cast<size_t>(4) * a.nstride;
   const double* nmat = SYM ? a.nsym : a.ninv;
   for (int pass = 0;; ++pass) {
     int ct0;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
       const int ct = (ct0 + NW * j < nct) ? ct0 + NW * j : ct0;
-      nb_ptr[j] = nmat + static_cast<size_t>(lk) * a.nbp + ct * 16 + lc;
+      nb_ptr[j] = nmat + static_cast<size_t>(lk) * a.nstride + ct * 16 + lc;
     }
     const double* va_ptr = vt + lk * TR + lc;
     // Software pipeline: the matrix fragments (L2, ~600 cycles away) are fetched FOUR k-steps
@@ -321,11 +326,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
   }
 }
 
+template <int RT, int CG, int MODE, int NW, bool SYM>
+__global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
+  extern __shared__ double smem[];
+  constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? ((16 * RT) / 3) * 3 : 16 * RT;
+  cl_form_tile<RT, CG, MODE, NW, SYM>(a, static_cast<int64_t>(blockIdx.x) * rows_used, smem);
+}
+
 // Uncorrelated errors (has_corr_errors False): sum(vec**2/var), vec/var (:412, :420).
 // One thread per row (MARGE) or per chain (TRIPLE), bands in ascending order like the
 // reference's builtin sum().
-__global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cl_form_diag_item(const ClFormArgs& a, const int64_t i) {
   if (a.mode == CL_ROWS_TRIPLE) {
     if (i >= a.n) return;
     double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -351,6 +362,10 @@ __global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
     }
     a.out[i] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
+  cl_form_diag_item(a, static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x);
 }
 
 // 1 + beam_err*ibeam*3/halfsteps for ibeam = -5..5 (ClData_CosmoMC.py:334), once per data set
@@ -388,8 +403,7 @@ __device__ __forceinline__ double cl_marge11(const double* c, int stride, const 
   return -2 * log(s / norm) + mn;
 }
 
-__global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cl_combine_chain(const ClCombineArgs& a, const int64_t c) {
   if (c >= a.n) return;
   double chisq;
   if (a.mode == CL_ROWS_MARGE) {
@@ -437,23 +451,69 @@ __global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
   if (a.lnl) a.lnl[c] = a.accumulate ? a.lnl[c] + (-neg) : (0.0 + (-neg));
 }
 
+__global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
+  cl_combine_chain(a, static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x);
+}
+
 // ---- band powers ----------------------------------------------------------------------------
-// BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i]     (q parameter-major [npar][n])
+// BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i] for the 16 chains of a block, on the FP64 matrix cores:
+// one 16 x 16 tile of (chains x bands) per wave and pass, accumulator preloaded with BP0, k-steps
+// of four bins in ascending order.  q: LDS [>= P][16] (bin-major, chain fastest - the A operand
+// layout A[i = l&15][k = l>>4]); K: global [npar][nbp], its fragments B[k = l>>4][j = l&15] are
+// row-contiguous 16-wide reads, fetched eight k-steps at a time ahead of the MFMAs that use
+// them; out[band * ostride + chain] for chains < nvalid (LDS tile of the fused sampler, or the
+// global band-major array of the batched path).  The same function serves k_cl_bandpower and
+// k_cl_mh_run, so both engines see the same band powers bit for bit.  All 64*NW threads call it.
+template <int NW>
+__device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double* __restrict__ K,
+                                           const double* __restrict__ bp0, int nb, int nbp,
+                                           double* out, int64_t ostride, int nvalid) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lk = lane >> 4, lc = lane & 15;
+  const int nct = nbp >> 4, ksteps = (P + 3) >> 2;
+  constexpr int KB = 8;                                    // k-steps per fetch batch
+  for (int ct = w; ct < nct; ct += NW) {
+    const int band = ct * 16 + lc;
+    const double c0 = (band < nb) ? bp0[band] : 0.0;
+    double4_t acc = double4_t{c0, c0, c0, c0};
+    const double* kp = K + static_cast<size_t>(lk) * nbp + band;
+    for (int k0 = 0; k0 < ksteps; k0 += KB) {
+      double bv[KB], av[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int b = 4 * (k0 + u) + lk;
+        const bool live = b < P;
+        bv[u] = live ? kp[static_cast<size_t>(4 * (k0 + u)) * nbp] : 0.0;
+        av[u] = live ? q[b * 16 + lc] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u)
+        if (k0 + u < ksteps)                               // uniform
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lk + 4 * i;
+      if (row < nvalid) out[static_cast<int64_t>(band) * ostride + row] = (band < nb) ? acc[i] : 0.0;
+    }
+  }
+}
+
+// batched path: q parameter-major [npar][n] -> bp [nbp][n]; a block of 256 threads per 16 chains
 __global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int nb, int nbp,
                                                       const double* __restrict__ q,
                                                       const double* __restrict__ K,
                                                       const double* __restrict__ bp0,
                                                       double* __restrict__ bp) {
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (c >= n) return;
-  double s = 0.0;
-  if (i < nb) {
-    s = bp0[i];
-#pragma unroll 8
-    for (int b = 0; b < npar; ++b) s = fma(q[static_cast<int64_t>(b) * n + c], K[b * nbp + i], s);
+  extern __shared__ double ql[];                           // [npar][16]
+  const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 16;
+  const int nvalid = static_cast<int>(n - c0 < 16 ? n - c0 : 16);
+  for (int e = threadIdx.x; e < npar * 16; e += 256) {
+    const int b = e >> 4, r = e & 15;
+    ql[e] = (r < nvalid) ? q[static_cast<int64_t>(b) * n + c0 + r] : 0.0;
   }
-  bp[static_cast<int64_t>(i) * n + c] = s;
+  __syncthreads();
+  cl_bp_tile<4>(ql, npar, K, bp0, nb, nbp, bp + c0, n, nvalid);
 }
 
 struct ClBinning {

@@ -1,0 +1,514 @@
+// Fused Metropolis-Hastings over the binned-C_l likelihood: ONE launch advances every chain by
+// nsteps steps (propose -> band powers -> delta rows -> MFMA quadratic form -> marginalisation
+// -> accept -> moments), where the step-wise engine (gmh_kernels.hpp + cl_kernels.hpp) needs five
+// dependent launches per step and is bound by their latency (profiles/r1_clbeam_summary.txt:
+// 38 us per step for 4096 chains, nb = 64).
+//
+// A block of 64*NW threads owns kClMhChains = 16 chains = the 16 rows of one MFMA tile.  Thread
+// (chain, group) keeps the position, proposal widths and running moments of its parameters
+// (group, group + G, ...) in registers for the whole launch; the proposal of a step goes to LDS
+// [P][16] as the A operand of the band-power MFMAs (cl_bp_tile, the function k_cl_bandpower
+// runs), the band powers to LDS as the row tile of cl_form_tile (the function k_cl_form runs):
+// a chain's log-likelihood comes out of the same instructions in the same order as in the
+// step-wise engine.  Every other piece (indices into the Philox streams, proposal arithmetic,
+// accept rule, Welford and co-moment updates) restates k_gmh_propose / k_gmh_accept, with the
+// free-running draws of several steps generated together into an LDS cache.
+// tests/test_cl_mh_fused_gpu.py holds the two engines to bit-identical chains in every proposal
+// mode and for every shape of the likelihood; tests/test_gmh_gpu.py runs the reference's own
+// chains (G5) through both, draw for draw.
+//
+// Instantiations: <NW, FORM, RES>.  One data set: compiled for its form (plain / symmetrised
+// MFMA form, analytic-marginalisation triple form, uncorrelated errors); RES = its N^-1, K and
+// band tables are copied into LDS at launch (grids of at most one block per CU: a step then
+// touches L2 / HBM only for traces and co-moments), else they are streamed from L2 and two blocks
+// share a CU.  Several data sets: the generic kernel (FORM = CLMH_ANY).
+//
+// Measured (MI355X, 4096 chains, nb = 64, 32 bins; profiles/r2_clmh_summary.txt): a step is a
+// chain of dependent LDS / MFMA / barrier latencies with one wave per SIMD - about 1250
+// instructions and 15 600 cycles per wave and step; halving the chains per block to double the
+// blocks per CU was measured and lost (10.9 vs 8.9 us per step: the idle tile rows cost more
+// than the overlap wins).
+//
+// Reference semantics: MCMC.py:225-286 (sample), Proposal.py:127-164 (getNewParams),
+// binnedClModel.py:125-132 (prior), ClData_CosmoMC.py:267-315 (calcLnLike), MCMC.py:290-340
+// (moments).
+#pragma once
+#include "cl_kernels.hpp"
+#include "gmh_device.hpp"
+
+namespace mi355 {
+
+constexpr int kClMhChains = 16;
+constexpr int kClMhMaxData = 4;      // data sets whose descriptors travel in the kernel arguments
+
+struct ClMhData {            // one data set (device pointers)
+  ClFormArgs f;              // its tables; bp / n / rows / out are filled in per block
+  const double* K;           // [npar][nbp]
+  const double* bp0;         // [nbp]
+  int has_corr;              // full covariance (MFMA form) or variances only
+  int rows_per_chain;        // 1 / 11 / 121 marginalisation points, or 3 (analytic: TRIPLE)
+  int sym;                   // the form of this data set runs on the symmetrised matrix
+  int pad;
+};
+
+struct ClMhArgs {
+  GmhArgs g;                 // chain state and proposal; step / nsamp / blk of the FIRST step;
+                             // inj_n / inj_u / tr_* are the bases of the whole run here
+  ClMhData data[kClMhMaxData];
+  int ndata;
+  int nbp_max;               // largest padded band count of the data sets
+  int fout_per_chain;        // doubles of form output per chain: max(rows_per_chain, 9)
+  int tile_doubles;          // LDS doubles of the form tile region (form_lds_bytes / 8)
+  int resident;              // 1: the (single) data set's matrices and tables are copied into LDS
+                             // at launch and every step reads them there
+  int sb;                    // steps whose Philox draws one refill of the draw cache covers
+  const double* weights;     // [11] margeweights
+  double margenorm;
+  int64_t nsteps;
+  int thin;
+  int64_t nkeep;
+};
+
+// Row stride (doubles) of the LDS copy of N^-1: = 16 (mod 32), so that the four 16-wide rows a
+// wave reads per MFMA operand fall on disjoint halves of the banks.
+__host__ __device__ inline int cl_mh_nstride(int nbp) { return (nbp % 32 == 0) ? nbp + 16 : nbp; }
+
+// LDS doubles of the resident copy of one data set: N^-1 (or the variances), K, BP0, obs,
+// x-factors, beam errors, the 11 beam-factor rows, has_xfactor bytes
+__host__ __device__ inline size_t cl_mh_resident_doubles(int P, int nbp, int has_corr) {
+  size_t n = has_corr ? static_cast<size_t>(nbp + 16) * cl_mh_nstride(nbp) : static_cast<size_t>(nbp);
+  n += static_cast<size_t>(P) * nbp + static_cast<size_t>(4 + kClGrid) * nbp + nbp / 8;
+  return n;
+}
+
+// doubles of dynamic LDS the kernel needs (host and device agree through this one function)
+__host__ __device__ inline size_t cl_mh_lds_doubles(int P, int nblock, int npn, int sb, int nbp_max,
+                                                    int fout_per_chain, int tile_doubles,
+                                                    size_t resident_doubles) {
+  const size_t CB = kClMhChains;
+  size_t n = static_cast<size_t>(tile_doubles) + static_cast<size_t>(nbp_max) * CB + fout_per_chain * CB;
+  n += 3 * static_cast<size_t>(P) * CB;                  // thn, dl, z
+  n += static_cast<size_t>(sb) * (npn + 1) * CB;         // draw cache: normals, uniforms
+  n += 4 * CB;                                           // lnPr, lnl, dec, spare
+  n += (3 * static_cast<size_t>(P) + 1) / 2 + 1;         // block_of, rank_in_block, cltype (int32)
+  n += CB;                                               // pbad (int32) + naccept (uint32)
+  n += (static_cast<size_t>(nblock > 0 ? nblock : 1) * CB + 1) / 2;   // accept counters (uint32)
+  return n + resident_doubles;
+}
+
+// parameters a thread keeps in registers: thread (chain, group) owns i = group + G * m, m < kClMhSlots
+constexpr int kClMhSlots = 4;
+
+// steps per refill of the draw cache: about two Philox blocks per thread and refill
+__host__ __device__ inline int cl_mh_cache_steps(int nthreads, int npn) {
+  int sb = (2 * nthreads / kClMhChains) / (npn > 0 ? npn : 1);
+  return sb < 1 ? 1 : (sb > 32 ? 32 : sb);
+}
+
+// Which form a resident (single data set) kernel is compiled for; the generic kernel (several data
+// sets, or matrices too large for LDS) dispatches at run time.
+enum ClMhForm : int { CLMH_ANY = 0, CLMH_MARGE = 1, CLMH_SYM = 2, CLMH_TRIPLE = 3, CLMH_DIAG = 4 };
+
+__host__ __device__ inline int cl_mh_form_kind(const ClMhData& D) {
+  if (!D.has_corr) return CLMH_DIAG;
+  if (D.f.mode == CL_ROWS_TRIPLE) return CLMH_TRIPLE;
+  return D.sym ? CLMH_SYM : CLMH_MARGE;
+}
+
+template <int NW, int FORM>
+__device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& f, double* tile) {
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x;
+  const int kind = FORM != CLMH_ANY ? FORM : cl_mh_form_kind(D);
+  if (kind == CLMH_DIAG) {
+    const int64_t work = (f.mode == CL_ROWS_TRIPLE) ? f.n : f.rows;
+    for (int64_t i = tid; i < work; i += NT) cl_form_diag_item(f, i);
+    return;
+  }
+  const int rows_used = (kind == CLMH_TRIPLE) ? 15 : 16;
+  const int ntiles = static_cast<int>((f.rows + rows_used - 1) / rows_used);
+  for (int it = 0; it < ntiles; ++it) {
+    if (it) __syncthreads();                             // the previous tile is done with `tile`
+    const int64_t row0 = static_cast<int64_t>(it) * rows_used;
+    if (kind == CLMH_TRIPLE) cl_form_tile<1, 1, CL_ROWS_TRIPLE, NW, false>(f, row0, tile);
+    else if (kind == CLMH_SYM) cl_form_tile<1, 1, CL_ROWS_MARGE, NW, true>(f, row0, tile);
+    else cl_form_tile<1, 1, CL_ROWS_MARGE, NW, false>(f, row0, tile);
+  }
+}
+
+template <int NW, int FORM, bool RES>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run(const ClMhArgs* __restrict__ ap) {
+  // The arguments live in device memory and are read where they are used (scalar loads): passed
+  // by value, the ~1 KB of pointers and counters stays in SGPRs for the whole launch and spills.
+  const ClMhArgs& a = *ap;
+  static_assert(!RES || FORM != CLMH_ANY, "a resident kernel is compiled for its form");
+  constexpr int NT = 64 * NW, CB = kClMhChains, G = NT / CB, MS = kClMhSlots;
+  extern __shared__ double smem[];
+  const GmhArgs& g = a.g;
+  const int P = g.pb.P;                                   // <= MS * G (host check)
+  const int64_t N = g.N;
+  const int tid = threadIdx.x, cl = tid & (CB - 1), grp = tid >> 4;
+  const int64_t nbase = static_cast<int64_t>(blockIdx.x) * CB;
+  const int64_t n = nbase + cl;
+  const bool valid = n < N;
+  const int nblk = g.nblock > 0 ? g.nblock : 1;
+
+  // ---- LDS carve-up (cl_mh_lds_doubles) ----
+  double* tile = smem;
+  double* bp = tile + a.tile_doubles;                    // [nbp_max][CB]
+  double* fout = bp + static_cast<size_t>(a.nbp_max) * CB;
+  double* thn = fout + a.fout_per_chain * CB;            // [P][CB]: the proposal (A operand of BP)
+  double* dl = thn + P * CB;                             // [P][CB]: x - mean, for the co-moments
+  double* z = dl + P * CB;                               // [P][CB]: injected normals (CORR / rotated)
+  double* zc = z + P * CB;                               // [sb * npn][CB] normals of the cached steps
+  double* uc = zc + static_cast<size_t>(a.sb) * g.npn * CB;   // [sb][CB] uniforms
+  double* lnpr = uc + static_cast<size_t>(a.sb) * CB;    // [CB] each
+  double* lnl = lnpr + CB;
+  double* dec = lnl + CB;
+  int32_t* block_of = reinterpret_cast<int32_t*>(dec + 2 * CB);
+  int32_t* rank_of = block_of + P;
+  int32_t* cltype = rank_of + P;
+  int32_t* pbad = reinterpret_cast<int32_t*>(dec + 2 * CB + (3 * static_cast<size_t>(P) + 1) / 2 + 1);
+  uint32_t* nacc = reinterpret_cast<uint32_t*>(pbad + CB);
+  uint32_t* accb = nacc + CB;                            // [nblk][CB]
+  double* resid = reinterpret_cast<double*>(pbad) + CB + (static_cast<size_t>(nblk) * CB + 1) / 2;
+
+  for (int i = tid; i < P; i += NT) {
+    block_of[i] = g.block_of[i];
+    rank_of[i] = g.rank_in_block[i];
+    cltype[i] = g.pb.cltype[i];
+  }
+  // chain state of the thread's parameters, in registers for the whole launch
+  double rth[MS], rsg[MS], rmu[MS], rm2[MS], rnew[MS];
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    const int i = grp + G * m;
+    const bool on = valid && i < P;
+    rth[m] = on ? g.theta[i * N + n] : 0.0;
+    rsg[m] = on ? g.sigma[i * N + n] : 0.0;
+    rmu[m] = on ? g.mean[i * N + n] : 0.0;
+    rm2[m] = on ? g.m2[i * N + n] : 0.0;
+    rnew[m] = rth[m];
+  }
+  for (int b = grp; b < nblk; b += G)
+    accb[b * CB + cl] = (valid && g.nblock) ? g.accept[static_cast<int64_t>(b) * N + n] : 0u;
+  if (grp == 0) {
+    lnpr[cl] = valid ? g.lnPr[n] : 0.0;
+    nacc[cl] = valid ? g.naccept[n] : 0u;
+    pbad[cl] = 0;
+  }
+  // RES: one data set whose matrices fit - N^-1 (the copy its form uses), K and the band tables
+  // move to LDS once per launch, and a step touches HBM / L2 only for the trace and the co-moments.
+  ClMhData D0 = a.data[0];
+  if constexpr (RES) {
+    const int nbp = D0.f.nbp, ns = cl_mh_nstride(nbp);
+    double* p = resid;
+    if (D0.has_corr) {
+      const double* src = D0.sym ? D0.f.nsym : D0.f.ninv;
+      for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[e];
+      D0.f.ninv = D0.f.nsym = p;
+      D0.f.nstride = ns;
+      p += static_cast<size_t>(nbp + 16) * ns;             // 16 rows of slack: the form fetches ahead
+    } else {
+      for (int e = tid; e < nbp; e += NT) p[e] = D0.f.var[e];
+      D0.f.var = p;
+      p += nbp;
+    }
+    for (int e = tid; e < P * nbp; e += NT) p[e] = D0.K[e];
+    D0.K = p;
+    p += static_cast<size_t>(P) * nbp;
+    double* t_bp0 = p;
+    double* t_obs = p + nbp;
+    double* t_xf = p + 2 * nbp;
+    double* t_be = p + 3 * nbp;
+    double* t_bf = p + 4 * nbp;
+    uint8_t* t_hx = reinterpret_cast<uint8_t*>(p + (4 + kClGrid) * nbp);
+    for (int e = tid; e < nbp; e += NT) {
+      t_bp0[e] = D0.bp0[e];
+      t_obs[e] = D0.f.obs[e];
+      t_xf[e] = D0.f.xf[e];
+      t_be[e] = D0.f.beam_err[e];
+      t_hx[e] = D0.f.hasx[e];
+    }
+    for (int e = tid; e < kClGrid * nbp; e += NT) t_bf[e] = D0.f.bfac[e];
+    D0.bp0 = t_bp0;
+    D0.f.obs = t_obs;
+    D0.f.xf = t_xf;
+    D0.f.beam_err = t_be;
+    D0.f.bfac = t_bf;
+    D0.f.hasx = t_hx;
+  }
+  __syncthreads();
+
+  const bool inject = g.inj_n != nullptr;
+  const double* e2t = kExp2Table;                          // accept test: as k_gmh_accept
+  int blk = g.blk;
+
+  // getNewParams (Proposal.py:127-164) + prior (binnedClModel.py:125-132) of step t into rnew / thn.
+  // Free-running draws: every sb steps all threads together fill the cache with normal(idx), idx in
+  // [step * npn, (step + sb) * npn), and uniform(step .. step + sb - 1) of the block's chains - the
+  // values philox_normal / philox_uniform return for those indices (one Philox block + Box-Muller
+  // serves both halves of a pair).
+  int ts = 0;                                              // t % sb, kept without a division
+  auto propose = [&](int64_t t) {
+    const int64_t step = g.step + t;
+    const uint64_t base = static_cast<uint64_t>(step) * g.npn;
+    const double* inj = inject ? g.inj_n + (t * N + n) * P : nullptr;   // this chain's row
+    auto in_block = [&](int i) { return g.nblock == 0 || block_of[i] == blk; };
+    if (!inject && ts == 0) {
+      const uint64_t idx0 = base, cnt = static_cast<uint64_t>(a.sb) * g.npn;
+      const uint64_t p0 = idx0 >> 1, np = ((idx0 + cnt - 1) >> 1) - p0 + 1;
+      const uint64_t s0 = static_cast<uint64_t>(step), q0 = s0 >> 1, nq = ((s0 + a.sb - 1) >> 1) - q0 + 1;
+      for (uint64_t it = tid; it < (np + nq) * CB; it += NT) {
+        const int c = static_cast<int>(it & (CB - 1));
+        const uint64_t q = it >> 4;
+        if (q < np) {
+          double za, zb;
+          philox_normal2(g.seed, RNG_NORMAL, nbase + c, p0 + q, za, zb);
+          const uint64_t ia = 2 * (p0 + q) - idx0;         // wraps below idx0: fails the range test
+          if (ia < cnt) zc[ia * CB + c] = za;
+          if (ia + 1 < cnt) zc[(ia + 1) * CB + c] = zb;
+        } else {
+          double ua, ub;
+          philox_uniform2(g.seed, RNG_UNIFORM, nbase + c, q0 + (q - np), ua, ub);
+          const uint64_t ia = 2 * (q0 + (q - np)) - s0;
+          if (ia < static_cast<uint64_t>(a.sb)) uc[ia * CB + c] = ua;
+          if (ia + 1 < static_cast<uint64_t>(a.sb)) uc[(ia + 1) * CB + c] = ub;
+        }
+      }
+      __syncthreads();
+    }
+    const double* zrow = zc + static_cast<size_t>(ts) * g.npn * CB + cl;   // normal(base + r) = zrow[r * CB]
+    if (g.mode == GMH_UNCORR) {
+#pragma unroll
+      for (int m = 0; m < MS; ++m) {
+        const int i = grp + G * m;
+        if (i < P) {
+          double v = rth[m];
+          if (in_block(i)) {                               // :151, :156-159
+            const double zi = valid ? (inject ? inj[i] : zrow[rank_of[i] * CB]) : 0.0;
+            v += zi * rsg[m];
+          }
+          rnew[m] = v;
+          thn[i * CB + cl] = v;
+          if (cltype[i] != 1 && v < 0) pbad[cl] = 1;
+        }
+      }
+    } else {
+      // z_j of the step: CORR normal(base + j) for every j, rotated normal(base + rank_j) for the
+      // block's members; injected rows are staged in z, free-running draws are read in the cache
+      if (inject) {
+        if (valid) {
+          for (int j = grp; j < P; j += G)
+            if (g.mode == GMH_CORR) z[j * CB + cl] = inj[j];
+            else if (in_block(j)) z[j * CB + cl] = inj[rank_of[j]];
+        }
+        __syncthreads();
+      }
+      auto zval = [&](int j) {
+        return inject ? z[j * CB + cl] : (g.mode == GMH_CORR ? zrow[j * CB] : zrow[rank_of[j] * CB]);
+      };
+#pragma unroll
+      for (int m = 0; m < MS; ++m) {
+        const int i = grp + G * m;
+        if (i < P) {
+          double v = rth[m];
+          if (valid) {
+            const double* Li = g.L + static_cast<int64_t>(i) * P * N + n;
+            if (g.mode == GMH_CORR) {
+              if (in_block(i)) {                           // :153-159
+                double s = 0.0;
+#pragma unroll 4
+                for (int j = 0; j < P; ++j) s += Li[j * N] * zval(j);
+                v += s * rsg[m];
+              }
+            } else {                                       // :145-148, sum() starts from 0
+              double s = 0.0;
+              for (int j = 0; j < P; ++j)
+                if (in_block(j)) s += Li[j * N] * zval(j);
+              v += s * rsg[m];
+            }
+          }
+          rnew[m] = v;
+          thn[i * CB + cl] = v;
+          if (cltype[i] != 1 && v < 0) pbad[cl] = 1;
+        }
+      }
+    }
+  };
+
+#ifdef MI355_CLMH_PROF
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  long long pc = clock64();
+#define CLMH_TICK(k) do { __syncthreads(); const long long now_ = clock64(); pt[k] += now_ - pc; pc = now_; } while (0)
+#else
+#define CLMH_TICK(k) do {} while (0)
+#endif
+  // -ln L of one data set for the proposals in thn -> lnl (accumulated over the data sets)
+  auto dataset = [&](const ClMhData& D, int id) {
+    // BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i] on the matrix cores (the function k_cl_bandpower runs)
+    cl_bp_tile<NW>(thn, P, D.K, D.bp0, D.f.nb, D.f.nbp, bp, CB, CB);
+    __syncthreads();
+    CLMH_TICK(1);
+    ClFormArgs f = D.f;
+    f.bp = bp;
+    f.n = CB;
+    f.rows = static_cast<int64_t>(CB) * D.rows_per_chain;
+    f.out = fout;
+    cl_mh_form<NW, FORM>(D, f, tile);
+    __syncthreads();
+    CLMH_TICK(2);
+    if (tid < CB) {
+      ClCombineArgs cmb{};
+      cmb.form = fout;
+      cmb.n = CB;
+      cmb.mode = f.mode;
+      cmb.ncal = f.ncal;
+      cmb.nbeam = f.nbeam;
+      cmb.beam_uncertain = f.beam_uncertain;
+      cmb.calib = f.calib;
+      cmb.weights = a.weights;
+      cmb.margenorm = a.margenorm;
+      cmb.lnl = lnl;
+      cmb.accumulate = id > 0 ? 1 : 0;
+      cmb.neglnl = nullptr;
+      cl_combine_chain(cmb, tid);
+    }
+    // (the next data set's band powers go to `bp`, which the combine does not read; its form
+    // output is written after the barrier that follows them)
+  };
+
+  int thin_ctr = 0;
+  int64_t row_next = 0;
+  for (int64_t t = 0; t < a.nsteps; ++t) {
+    // the proposal follows the previous step's moment update without a barrier: it needs this
+    // thread's own registers only
+    propose(t);
+    __syncthreads();
+    CLMH_TICK(0);
+    // ---- lnLike(q) summed over the data sets (binnedClLikelihood.py:26-32) ----
+    if constexpr (FORM != CLMH_ANY) {
+      dataset(D0, 0);
+    } else {
+      for (int id = 0; id < a.ndata; ++id) dataset(a.data[id], id);
+    }
+
+    // ---- accept / reject (MCMC.py:236-279); thread tid < CB is chain cl = tid ----
+    bool keep = false;                                     // (t + 1) % thin == 0, rows < nkeep
+    if (a.thin > 0 && ++thin_ctr == a.thin) {
+      thin_ctr = 0;
+      keep = row_next < a.nkeep;
+    }
+    const int64_t row = row_next;
+    if (keep) ++row_next;
+    if (tid < CB) {
+      bool accepted = false;
+      if (valid) {
+        const double prior = pbad[cl] ? 0.0 : 1.0;
+        const double v = lnl[cl];
+        const double prev = lnpr[cl];
+        const bool bad = (v != v) || (v == -__builtin_inf());   // :238-243
+        if (prior > 0.0 && !bad) {
+          const double lnalpha = v - prev;                 // :251-252 (prior is 1: nothing to add)
+          bool reject = false;
+          if (!(lnalpha >= 0.0)) {
+            const double u = g.inj_u ? g.inj_u[t * N + n]
+                                     : uc[ts * CB + cl];                        // = uniform(step)
+            reject = !(exp_accept(lnalpha, e2t) > u);      // :264
+          }
+          accepted = !reject;
+        }
+        if (accepted) {
+          lnpr[cl] = v;
+          nacc[cl] += 1;                                   // :269
+          if (g.nblock) accb[blk * CB + cl] += 1;          // :271
+        }
+        if (keep) {
+          g.tr_lnPr[row * N + n] = accepted ? v : prev;
+          g.tr_acc[row * N + n] = accepted ? 1 : 0;
+        }
+      }
+      dec[cl] = accepted ? 1.0 : 0.0;
+      pbad[cl] = 0;
+    }
+    __syncthreads();
+    CLMH_TICK(3);
+
+    // ---- position, running moments (MCMC.py:290-340), trace: registers only ----
+    const double cnt = static_cast<double>(g.nsamp + t + 1);
+    const double rn = rcp_nr(cnt);                         // as k_gmh_accept / the fused SED kernel
+    const double cf = 1.0 - rn;
+    {
+      const bool accepted = dec[cl] != 0.0;
+#pragma unroll
+      for (int m = 0; m < MS; ++m) {
+        const int i = grp + G * m;
+        if (i < P) {
+          const double x = accepted ? rnew[m] : rth[m];
+          rth[m] = x;
+          const double dlt = x - rmu[m];
+          if (g.comom != nullptr) dl[i * CB + cl] = dlt;
+          rmu[m] = fma(dlt, rn, rmu[m]);
+          rm2[m] = fma(dlt, x - rmu[m], rm2[m]);
+          if (keep && valid) g.tr_theta[(row * P + i) * N + n] = x;
+        }
+      }
+    }
+    if (g.comom != nullptr) {                              // uniform over the grid
+      __syncthreads();
+      if (valid) {
+        // C_ij += (n-1)/n d_i d_j, lower triangle dealt round-robin to the groups (k_gmh_accept)
+        const int T = P * (P + 1) / 2;
+        constexpr int U = 8;
+        for (int e0 = grp; e0 < T; e0 += G * U) {
+          double* ptr[U];
+          double inc[U], cur[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * G;
+            ptr[u] = nullptr;
+            if (e < T) {
+              int i, j;
+              gmh_tri_decode(e, i, j);
+              ptr[u] = g.comom + (static_cast<int64_t>(i) * P + j) * N + n;
+              inc[u] = cf * dl[i * CB + cl] * dl[j * CB + cl];
+              cur[u] = *ptr[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (ptr[u]) *ptr[u] = cur[u] + inc[u];
+        }
+      }
+    }
+    if (g.nblock) blk = (blk + 1 == g.nblock) ? 0 : blk + 1;   // MCMC.py:278-279
+    ts = (ts + 1 == a.sb) ? 0 : ts + 1;
+  }
+#ifdef MI355_CLMH_PROF
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+    printf("clmh block %d steps %lld: moments+propose %lld bp %lld form %lld accept %lld (ticks per step)\n",
+           blockIdx.x, (long long)a.nsteps, pt[0] / a.nsteps, pt[1] / a.nsteps, pt[2] / a.nsteps,
+           pt[3] / a.nsteps);
+#endif
+
+  // ---- state back to HBM ----
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      const int i = grp + G * m;
+      if (i < P) {
+        g.theta[i * N + n] = rth[m];
+        g.mean[i * N + n] = rmu[m];
+        g.m2[i * N + n] = rm2[m];
+      }
+    }
+    if (g.nblock)
+      for (int b = grp; b < nblk; b += G) g.accept[static_cast<int64_t>(b) * N + n] = accb[b * CB + cl];
+    if (grp == 0) {
+      g.lnPr[n] = lnpr[cl];
+      g.naccept[n] = nacc[cl];
+    }
+  }
+}
+
+}  // namespace mi355

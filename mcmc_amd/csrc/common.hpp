@@ -138,6 +138,7 @@ struct mi355_ctx {
   int32_t rank_in_block[mi355::kMaxParam] = {0};
   int npn = 1;                    // normals drawn per step in free-running mode
   bool incremental = false;       // mi355_mh_set_incremental: k_mh_run_inc where it applies
+  bool mh_fused = true;           // mi355_mh_set_fused: step-wise problems run their fused kernel where one exists
   int64_t step_total = 0;         // Philox stream position (never reset)
   int64_t stage_step = 0;         // steps since the last init/adapt (iBlock = stage_step % nblock)
   int64_t stage = 0;              // number of init/adapt calls (keys the start stream)

@@ -218,6 +218,29 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     const size_t rows = static_cast<size_t>(c->nkeep) * N;
     if (c->tr_theta.alloc(rows * P) || c->tr_lnPr.alloc(rows) || c->tr_acc.alloc(rows)) return -2;
   }
+  if (g->pb.kind == GMH_CL && c->mh_fused && cl_mh_fused_nw(c, P, c->nblock, c->npn) > 0) {
+    // binnedCl: the whole run in one launch of the fused kernel (cl_mh_kernels.hpp)
+    GmhArgs a = base_args(c);
+    a.blk = c->nblock ? static_cast<int>(c->stage_step % c->nblock) : 0;
+    a.step = c->step_total;
+    a.nsamp = c->nsamp;
+    if (inj_n) {
+      a.inj_n = g->stage_a.p;
+      a.inj_u = g->stage_b.p;
+    }
+    if (c->nkeep > 0) {
+      a.tr_theta = c->tr_theta.p;
+      a.tr_lnPr = c->tr_lnPr.p;
+      a.tr_acc = c->tr_acc.p;
+    }
+    const int rc = cl_mh_run(c, a, nsteps, c->nkeep > 0 ? thin : 0, c->nkeep);
+    if (rc) return rc;
+    c->step_total += nsteps;
+    c->stage_step += nsteps;
+    c->nsamp += nsteps;
+    MI355_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   int64_t row = 0;
   int64_t t0 = 0;
   if (!inj_n && c->nkeep == 0 && nsteps >= kGraphMinSteps) {
@@ -486,5 +509,16 @@ int mi355_mh_get_sqrt_matrix(mi355_ctx* c, double* L) {
 }
 
 int32_t mi355_mh_proposal_mode(mi355_ctx* c) { return gmh_active(c) ? c->gmh->mode : 0; }
+
+int mi355_mh_set_fused(mi355_ctx* c, int32_t on) {
+  MI355_REQUIRE(c, "null context");
+  c->mh_fused = on != 0;
+  return 0;
+}
+
+int mi355_mh_fused_active(mi355_ctx* c) {
+  if (!gmh_active(c) || !c->mh_ready || !c->mh_fused) return 0;
+  return (c->gmh->pb.kind == GMH_CL && cl_mh_fused_nw(c, c->gmh->pb.P, c->nblock, c->npn) > 0) ? 1 : 0;
+}
 
 }  // extern "C"

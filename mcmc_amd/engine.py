@@ -278,6 +278,15 @@ class Engine:
         the two-component models in single-parameter block mode"""
         check(self.lib.mi355_mh_set_incremental(self._h, 1 if on else 0))
 
+    def mh_set_fused(self, on=True):
+        """one-launch runs of step-wise problems where a fused kernel exists (binnedCl); on by
+        default, off forces the launch-per-step engine (mi355_mh_set_fused)"""
+        check(self.lib.mi355_mh_set_fused(self._h, 1 if on else 0))
+
+    @property
+    def mh_fused_active(self):
+        return bool(self.lib.mi355_mh_fused_active(self._h))
+
     @property
     def mh_incremental_active(self):
         return bool(self.lib.mi355_mh_incremental_active(self._h))

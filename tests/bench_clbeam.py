@@ -81,21 +81,26 @@ def bench_beam(M=2000, side=256, C=16, reps=3):
                           "lnl_finite": bool(torch.isfinite(out).all().item())}))
 
 
-def bench_mh(nb=64, npar=32, calib=0.0, beam=0.0, chains=4096, nsteps=300):
-    """MH steps/s of the step-wise engine on a Cl problem (launch-bound when the likelihood is small)."""
+def bench_mh(nb=64, npar=32, calib=0.0, beam=0.0, chains=4096, nsteps=300, fused=1, track_cov=0):
+    """MH steps/s on a Cl problem: the fused one-launch kernel (fused=1) or the launch-per-step
+    engine (fused=0, launch-bound when the likelihood is small)."""
     from oracle import refcl as RC
     from mcmc_amd import Engine
     model, d, truth = RC.synth_cl_problem(nb=nb, npar=npar, calib=calib, beam=beam, lmax=2400)
     with Engine() as eng:
         eng.cl_load([d])
         eng.cl_set_binning(model.bins, model.shapefun)
-        eng.mh_init_problem("cl", chains, truth, np.full(npar, 0.02), param_blocks=np.arange(npar))
+        eng.mh_set_fused(bool(fused))
+        eng.mh_init_problem("cl", chains, truth, np.full(npar, 0.02), param_blocks=np.arange(npar),
+                            track_cov=bool(track_cov))
         eng.mh_run(20)
         t0 = time.perf_counter()
         eng.mh_run(nsteps)
         dt = time.perf_counter() - t0
         mom = eng.mh_moments()
-        print(json.dumps({"workload": "Cl step-wise MH", "chains": chains, "nb": nb, "npar": npar,
+        print(json.dumps({"workload": "Cl MH, fused kernel" if eng.mh_fused_active else "Cl MH, launch per step",
+                          "chains": chains, "nb": nb, "npar": npar, "track_cov": int(track_cov),
+                          "calib": calib, "beam": beam,
                           "us_per_step": dt / nsteps * 1e6, "chain_steps_per_s": chains * nsteps / dt,
                           "accept": float(mom["naccept"].mean() / (nsteps + 21))}))
 

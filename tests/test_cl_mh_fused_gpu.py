@@ -1,0 +1,134 @@
+"""The fused binnedCl Metropolis-Hastings kernel (csrc/cl_mh_kernels.hpp: a whole mh_run in one
+launch, chain state in LDS) against the step-wise engine it replaces (five launches per step):
+same draws, same arithmetic, so the chains must be identical bit for bit - in every proposal mode
+of Proposal.py:127-164, for every shape of ClData_CosmoMC.calcLnLike (:267-315: plain, 11-point
+calibration grid, analytic marginalisation, uncorrelated errors, two data sets, symmetrised-matrix
+form from 128 bands up), with co-moments, traces and injected draws.  The reference's own chains
+(G5) through the fused kernel: tests/test_gmh_gpu.py."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(kind):
+    from oracle import refcl as RC
+    if kind == "plain":                                   # x-factors, no marginalisation: 1 row per chain
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.0, beam=0.0, lmax=700, seed=5)
+        return model, [d], truth
+    if kind == "calib11":                                 # 11-point calibration grid
+        model, d, truth = RC.synth_cl_problem(nb=40, npar=7, calib=0.05, beam=0.0, lmax=900, seed=6)
+        return model, [d], truth
+    if kind == "beam11":                                  # 11-point beam grid (calib exactly 0)
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=5, calib=0.0, beam=0.02, lmax=700, seed=7)
+        return model, [d], truth
+    if kind == "analytic":                                # no x-factors: analytic calib + beam (TRIPLE rows)
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=8,
+                                              with_x=False)
+        return model, [d], truth
+    if kind == "diag":                                    # uncorrelated errors
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.0, lmax=700, seed=9)
+        var = 1.0 / np.diag(d.N_inv)
+        return model, [dataclasses.replace(d, N_inv=None, var=var)], truth
+    if kind == "two":                                     # two data sets, different marginalisations
+        model, d1, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.0, beam=0.0, lmax=700, seed=5)
+        _, d2, _ = RC.synth_cl_problem(nb=40, npar=6, calib=0.05, beam=0.02, lmax=700, seed=11, with_x=False)
+        return model, [d1, d2], truth
+    if kind == "sym144":                                  # 9 column tiles: 8 waves, symmetrised matrix
+        model, d, truth = RC.synth_cl_problem(nb=144, npar=12, calib=0.0, beam=0.0, lmax=2400, seed=12)
+        return model, [d], truth
+    if kind == "wide96":                                  # 6 column tiles: 8 waves, plain matrix
+        model, d, truth = RC.synth_cl_problem(nb=96, npar=33, calib=0.0, beam=0.0, lmax=2400, seed=13)
+        return model, [d], truth
+    raise ValueError(kind)
+
+
+def run(kind, fused, mode, C, track_cov, inject=None, seed=97):
+    from mcmc_amd import Engine
+    model, data, truth = problem(kind)
+    P = model.nparam
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    block = mode != "corr_all"
+    out = {}
+    with Engine(seed=seed) as eng:
+        eng.mh_set_fused(fused)
+        eng.cl_load(data)
+        eng.cl_set_binning(model.bins, model.shapefun)
+        eng.mh_init_problem("cl", C, truth, np.full(P, 0.02), param_blocks=np.arange(P) if block else None,
+                            track_cov=track_cov)
+        assert eng.mh_fused_active == fused
+        if mode != "uncorr_block":
+            eng.mh_set_sqrt_matrix(L, rotate=(mode == "rotate_block"))
+        if inject is None:
+            eng.mh_run(37, thin=1)
+            out["trace1"] = eng.mh_trace()
+            eng.mh_run(45)                                # no trace; the graph path of the step-wise engine
+            eng.mh_run(21, thin=3)
+            out["trace2"] = eng.mh_trace()
+        else:
+            zn, zu = inject
+            eng.mh_run(zn.shape[0], thin=1, inj_normals=zn, inj_uniforms=zu)
+            out["trace1"] = eng.mh_trace()
+        out["mom"] = eng.mh_moments()
+        if track_cov:
+            out["cov"] = eng.mh_covar(normalized=False)
+            eng.mh_adapt_corr(rotate=block)               # newMCMC on the device, then more steps
+            eng.mh_run(30)
+            out["mom2"] = eng.mh_moments()
+            out["L"] = eng.mh_sqrt_matrix()
+    return out
+
+
+def same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, dict):
+            for kk in x:
+                assert np.array_equal(x[kk], y[kk], equal_nan=True), (k, kk)
+        elif isinstance(x, tuple):
+            for i, (u, v) in enumerate(zip(x, y)):
+                assert np.array_equal(u, v, equal_nan=True), (k, i)
+        else:
+            assert np.array_equal(x, y, equal_nan=True), k
+
+
+@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96"])
+def test_fused_equals_stepwise_every_likelihood_shape(kind):
+    C = 40 if kind != "sym144" else 19                    # not a multiple of the 16 chains of a block
+    same(run(kind, True, "uncorr_block", C, False), run(kind, False, "uncorr_block", C, False))
+
+
+@pytest.mark.parametrize("mode", ["uncorr_block", "corr_all", "rotate_block"])
+def test_fused_equals_stepwise_every_proposal_mode(mode):
+    same(run("plain", True, mode, 37, True), run("plain", False, mode, 37, True))
+
+
+def test_fused_equals_stepwise_with_injected_draws():
+    rng = np.random.default_rng(12)
+    n, C, P = 50, 5, 7
+    zn = rng.standard_normal((n, C, P))
+    zu = rng.uniform(size=(n, C))
+    for mode in ("uncorr_block", "corr_all", "rotate_block"):
+        same(run("calib11", True, mode, C, False, inject=(zn, zu)),
+             run("calib11", False, mode, C, False, inject=(zn, zu)))
+
+
+def test_problems_beyond_the_fused_kernel_fall_back_to_the_stepwise_engine():
+    """121 marginalisation points per chain: batched kernels (step-wise engine), by design."""
+    from oracle import refcl as RC
+    from mcmc_amd import Engine
+    model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=5)
+    with Engine(seed=1) as eng:
+        eng.cl_load([d])
+        eng.cl_set_binning(model.bins, model.shapefun)
+        eng.mh_init_problem("cl", 8, truth, np.full(6, 0.02), param_blocks=np.arange(6))
+        assert not eng.mh_fused_active
+        eng.mh_run(40)
+        assert np.all(np.isfinite(eng.mh_moments()["lnPr"]))

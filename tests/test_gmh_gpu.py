@@ -46,16 +46,22 @@ def cl_engine(g, name="xcalib"):
     return eng, model
 
 
-def test_cl_reference_chains_block_rotated_correlated():
+@pytest.mark.parametrize("fused", [True, False])
+def test_cl_reference_chains_block_rotated_correlated(fused):
+    """The reference's own binnedCl chains (G5: doBlock, then rotated, then Cholesky-correlated
+    proposals, 11-point calibration marginalisation) draw for draw - through the fused one-launch
+    kernel (csrc/cl_mh_kernels.hpp) and through the launch-per-step engine."""
     g = load("cl_g5.npz")
     eng, model = cl_engine(g)
     P = model.nparam
     k = g["chain__k"]
     blocks = np.arange(P)
     with eng:
+        eng.mh_set_fused(fused)
         # stage 0: doBlock, uncorrelated, 400 steps of the reference's chain
         eng.mh_init_problem("cl", 1, g["chain__c0_samples"][0], np.full(P, 0.05), param_blocks=blocks,
                             randomize_start=False, track_cov=True)
+        assert eng.mh_fused_active == fused
         mom = replay(eng, g, "c0", k[0], 400, P)
         assert np.array_equal(mom["accept"][0, 0], g["chain__accept0"])
         # newMCMC(rotateParams=True) on the device: sigma = 2.4/sqrt(P)*stdev, Cholesky of the
