@@ -366,6 +366,17 @@ int mi355_gelman_rubin(mi355_ctx* ctx, int32_t nchain, int32_t P, const double* 
 int mi355_mh_ess(mi355_ctx* ctx, double* ess);
 /* Single-GPU convenience: all C chains are local.  rhat host [S, P]. */
 int mi355_rhat(mi355_ctx* ctx, double* rhat);
+/* mi355_rhat for callers that cannot allocate.  It has no counterpart in the reference; it is for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
+ * kernels as mi355_rhat, but the intermediates (chain-mean sums, centred sums) live in a fixed
+ * device array of the library (24 MB per GPU, held until the process ends) and the result stays
+ * on the device: rhat_dev [P, S] (the layout of mi355_rhat_finish_async).  The call makes no
+ * hipMalloc / hipFree and no host allocation, and is asynchronous on the context stream.
+ * Limit: S * P <= MI355_RHAT_NOALLOC_MAX, otherwise an error (mi355_rhat has no such limit).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two contexts, two
+ * streams) race - serialise them. */
+#define MI355_RHAT_NOALLOC_MAX 1048576
+int mi355_rhat_noalloc_async(mi355_ctx* ctx, double* rhat_dev);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,12 @@ void set_error(const char* fmt, ...) {
 
 static const int kModelNParam[MI355_SED_NMODEL] = {3, 3, 6, 6, 2, 4, 4, 4};
 
+// Fixed scratch of mi355_rhat_noalloc_async: [3][MI355_RHAT_NOALLOC_MAX] doubles (24 MB) that
+// every GPU the library runs on holds until the process ends.  `scratch` is a host-side stand-in,
+// not a device address: host code only ever uses the pointer hipGetSymbolAddress returned for the
+// context's device (mi355_ctx::fixed_scratch).
+static __device__ __align__(256) double scratch[3 * MI355_RHAT_NOALLOC_MAX];
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr size_t kLdsLimit = 64 * 1024 - kExp2Entries * sizeof(double);   // dynamic LDS a block may ask for without opt-in (static: the 16 KB 2^y table)
@@ -233,6 +239,13 @@ int mi355_init(int device, uint64_t seed, mi355_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e != hipSuccess) {
     set_error("stream/event creation failed: %s", hipGetErrorString(e));
+    mi355_free(c);
+    return -2;
+  }
+  // this device's copy of the fixed scratch array (each GPU has its own, at its own address)
+  e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->fixed_scratch), HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !c->fixed_scratch) {
+    set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
     mi355_free(c);
     return -2;
   }
@@ -859,6 +872,28 @@ int mi355_mh_ess(mi355_ctx* c, double* ess) {
   for (int p = 0; p < P; ++p)
     for (int64_t s = 0; s < c->mhS; ++s) ess[s * P + p] = h[p * c->mhS + s];
   return 0;
+}
+
+int mi355_rhat_noalloc_async(mi355_ctx* c, double* rhat_dev) {
+  MI355_REQUIRE(c && c->mh_ready && rhat_dev, "mi355_rhat_noalloc_async: bad argument");
+  const int64_t n = c->mhS * c->mhP;
+  MI355_REQUIRE(n <= MI355_RHAT_NOALLOC_MAX,
+                "mi355_rhat_noalloc_async: %lld sources x %d parameters = %lld entries, the fixed "
+                "scratch holds %lld (use mi355_rhat, which allocates)", static_cast<long long>(c->mhS),
+                c->mhP, static_cast<long long>(n), static_cast<long long>(MI355_RHAT_NOALLOC_MAX));
+  MI355_HIP(hipSetDevice(c->device));
+  // every entry of gmean / sums is written by k_rhat_partial before it is read: nothing in the
+  // array has to start at zero, whatever the previous call left there
+  double* gmean = c->fixed_scratch;
+  double* sums = c->fixed_scratch + MI355_RHAT_NOALLOC_MAX;
+  int rc = mi355_rhat_partial_async(c, 0, nullptr, gmean);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scale, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, c->stream,
+                     n, 1.0 / static_cast<double>(c->C), gmean);
+  MI355_HIP(hipGetLastError());
+  rc = mi355_rhat_partial_async(c, 1, gmean, sums);
+  if (rc) return rc;
+  return mi355_rhat_finish_async(c, sums, c->C, rhat_dev);
 }
 
 int mi355_rhat(mi355_ctx* c, double* rhat) {

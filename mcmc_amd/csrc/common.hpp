@@ -154,6 +154,9 @@ struct mi355_ctx {
 
   // --- scratch ------------------------------------------------------------------------
   mi355::DevBuf<double> scratch_a, scratch_b, scratch_c;
+  // device address of the library's fixed scratch array on this context's GPU (api.hip:
+  // mi355_rhat_noalloc_async); resolved once at mi355_init with the device current
+  double* fixed_scratch = nullptr;
 
   // --- other problem kinds (owned; each lives in its own translation unit) -----------------
   mi355::ClProblem* cl = nullptr;       // binnedCl / ClData band-power likelihood

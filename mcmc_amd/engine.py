@@ -558,6 +558,11 @@ class Engine:
         check(self.lib.mi355_rhat(self._h, _dp(out)))
         return out
 
+    def rhat_noalloc(self, rhat_ptr):
+        """mi355_rhat with no allocation anywhere: result [P, S] into device memory at rhat_ptr,
+        asynchronous on the engine's stream (sync() before reading)."""
+        check(self.lib.mi355_rhat_noalloc_async(self._h, C.c_void_p(rhat_ptr)))
+
     def mh_ess(self):
         """Effective sample size [S, P] from the trace of the last mh_run (BDA3 11.5)."""
         out = np.empty((self.S, self.P))
