@@ -33,23 +33,26 @@ PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vec
 HBM_BYTES_PER_CHAIN_LAUNCH = 415.7
 
 
-def cpu_baseline(nu, d, sig, seconds=12.0):
-    """The oracle's one-step-at-a-time sampler (same call structure as MCMC.py:209-215) on the
-    first sources of the same catalogue, timed on one host core."""
+def _port_worker(job):
+    """one-step-at-a-time oracle chains on sources first, first+stride, ... for `seconds`:
+    (MH steps done, seconds used, ESS summed, sources touched)"""
     from oracle import refcpu as R
     from mcmc_amd import synth
-    nsrc, done, t_used, ess_sum = 0, 0, 0.0, 0.0
+    first, stride, seconds, nsources = job
+    nu, d, sig, _ = synth.sed_catalogue(min(nsources, first + 64 * stride + 1))
+    src, done, t_used, ess_sum, nsrc = first, 0, 0.0, 0.0, 0
     chunk = 500
     t_end = time.perf_counter() + seconds
-    while time.perf_counter() < t_end and nsrc < nu.shape[0]:
-        data = R.GaussData(nu[nsrc], d[nsrc], sig[nsrc])
+    while time.perf_counter() < t_end and src < nu.shape[0]:
+        data = R.GaussData(nu[src], d[src], sig[src])
         ch = R.Chain(R.sed_problem(R.M2N, data), synth.M2N_PROP_SIGMAS, synth.M2N_START,
-                     R.NumpyDraws(nsrc), do_block=True)
+                     R.NumpyDraws(src), do_block=True)
         t0 = time.perf_counter()
         while time.perf_counter() < t_end and len(ch.samples) < 4000:
             ch.run(chunk)
             done += chunk
         t_used += time.perf_counter() - t0
+        src += stride
         nsrc += 1
         # same ESS estimator as the GPU line (BDA3 11.5), on this chain thinned to <= 128 rows
         tr = np.asarray(ch.samples)[1:]
@@ -58,17 +61,46 @@ def cpu_baseline(nu, d, sig, seconds=12.0):
             e = np.array([R.ess_bda3(tr[:, i]) for i in range(tr.shape[1])])
             if np.any(np.isfinite(e)):
                 ess_sum += float(np.nanmin(e))
-    ess_rate = ess_sum / t_used if t_used > 0 else None
-    out = {"value": done / t_used, "unit": "evals/s", "cores": 1, "kind": "port",
-           "ess_per_sec": ess_rate,
-           "sample": "%d MH steps of oracle/refcpu.py (pure Python+NumPy restatement, one step "
-                     "at a time) on the first %d sources of the same catalogue, 1 chain each, "
-                     "%.1f s" % (done, nsrc, t_used)}
-    out.update(cpu_vectorised(seconds=4.0))
+    return done, t_used, ess_sum, nsrc
+
+
+def cpu_baseline(nsources, seconds=6.0):
+    """the oracle's one-step-at-a-time sampler (same call structure as
+    MCMC.py:209-215 -> Likelihood.py:99-105 -> model.py:394-396) on sources of the same catalogue,
+    on one host core and on every core of the box's CPU share (sources dealt to the processes);
+    then the NumPy-vectorised variant.  Forks: must run before this process touches the GPU."""
+    import multiprocessing as mp
+    cores = max(1, min(16, os.cpu_count() or 1))
+    done, t_used, ess_sum, nsrc = _port_worker((0, 1, seconds, nsources))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_port_worker, [(k, cores, seconds, nsources) for k in range(cores)])
+    all_rate = sum(r[0] / r[1] for r in res if r[1] > 0)
+    out = {"value": all_rate, "unit": "evals/s", "cores": cores, "kind": "port",
+           "per_core": all_rate / cores,
+           "one_core": {"value": done / t_used, "cores": 1,
+                        "ess_per_sec": ess_sum / t_used if t_used > 0 else None},
+           "ess_per_sec": sum(r[2] for r in res) / max(r[1] for r in res),
+           "sample": "oracle/refcpu.py (pure Python + NumPy restatement of the reference's sampler, one "
+                     "MH step at a time) on %d processes, %d MH steps on %d sources of the same "
+                     "catalogue, 1 chain each, %.1f s; before that %d steps on one core (%.1f s)"
+                     % (cores, sum(r[0] for r in res), sum(r[3] for r in res), max(r[1] for r in res),
+                        done, t_used)}
+    # speed of this port relative to the reference itself, measured once in the build container
+    # (oracle/time_port_vs_reference.py; the reference does not travel to the GPU box)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "port_over_reference.json")) as f:
+            por = json.load(f)
+        out["port_over_reference"] = por["port_over_reference"]
+        out["port_over_reference_note"] = ("refcpu.Chain %.3g vs reference MCMC.MC_append %.3g MH steps/s on "
+                                           "one core of the build container (%s)"
+                                           % (por["port_steps_per_s"], por["reference_steps_per_s"], por["where"]))
+    except (OSError, KeyError, ValueError):
+        pass
+    out.update(cpu_vectorised(seconds=3.0))
     return out
 
 
-def cpu_vectorised(seconds=4.0):
+def cpu_vectorised(seconds=3.0):
     """SURVEY 8(d)'s "best-effort CPU" lines: the same MH transition vectorised with NumPy over
     64 sources x 64 chains per process (oracle/refcpu.VectorChainsM2N), on one core and on the
     box's CPU share.  Must run before this process touches the GPU (it forks workers)."""
@@ -92,25 +124,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)   # x 200 = the 10 000 measured MH steps of SURVEY 8(d)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sources", type=int, default=100000)
-    ap.add_argument("--chains", type=int, default=64)
+    ap.add_argument("--config", choices=["auto", "C2", "C3"], default="auto",
+                    help="C2: 1e5 sources x 64 chains per GPU; C3: 1e6 sources x 32 chains per GPU "
+                         "(= BASELINE's 1e6 x 256 on 8 GPUs, chain-sharded, R-hat all-reduced over RCCL); "
+                         "auto: C2 on one GPU, C3's layout on several")
+    ap.add_argument("--sources", type=int, default=0, help="override the config's sources per GPU")
+    ap.add_argument("--chains", type=int, default=0, help="override the config's chains per source per GPU")
+    ap.add_argument("--dump-rhat", default="", help="rank 0 writes the last R-hat [S,P] to this .npy (tests)")
     ap.add_argument("--inner", type=int, default=200, help="MH steps per chain per launch")
     ap.add_argument("--adapt", type=int, default=2000, help="untimed stage-0 steps before newMCMC (SURVEY 8(d): 2 000)")
-    ap.add_argument("--ess-steps", type=int, default=2000,
+    ap.add_argument("--ess-steps", type=int, default=10000,
                     help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
     ap.add_argument("--incremental-steps", type=int, default=3,
                     help="extra launches with the opt-in incremental sampler (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     args = ap.parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    config = args.config if args.config != "auto" else ("C2" if world_env == 1 else "C3")
+    args.sources = args.sources or (100000 if config == "C2" else 1000000)
+    args.chains = args.chains or (64 if config == "C2" else 32)
 
     # CPU baselines first: the multi-core line forks workers, which must happen before this
     # process initialises the GPU.  N=1 only (rank 0 of a single-process run).
     cpu = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        from mcmc_amd import synth as _synth
-        nu0, d0, sig0, _ = _synth.sed_catalogue(args.sources)
-        cpu = cpu_baseline(nu0, d0, sig0, args.cpu_seconds)
+        cpu = cpu_baseline(args.sources, args.cpu_seconds)
 
     # stdout carries exactly one JSON line: libraries that write to file descriptor 1 (RCCL prints
     # a version banner there when the first communicator is made) are sent to stderr instead
@@ -205,7 +244,9 @@ def main():
     # source the minimum over parameters, summed over sources and (chains being independent) ranks
     ess_out = {}
     if args.ess_steps > 0:
-        thin = max(1, args.ess_steps // 100)
+        # thinned trace rows per chain: 100, fewer when the trace [rows, P, N] would pass 32 GB
+        rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+        thin = max(1, args.ess_steps // rows)
         eng.mh_run(100, thin=1)                               # allocates the trace buffers, untimed
         barrier()
         t1 = time.perf_counter()
@@ -224,6 +265,8 @@ def main():
             ess_total = float(tot[0].item())
         ess_out = {"ess_per_sec": ess_total / t_ess, "ess_steps": args.ess_steps, "ess_thin": thin,
                    "ess_median_per_source": float(np.nanmedian(ess_min)),
+                   "ess_caveat": "BDA3 ESS is only meaningful for sources whose chains have converged: "
+                                 "read it together with rhat_lt_1p1_frac",
                    "ess_note": "sum over sources of min-over-parameters ESS (BDA3 11.5 multi-chain "
                                "estimator on the device, %d chains x %d thinned rows per source per "
                                "GPU) / wall time of that run incl. the estimator" % (C, args.ess_steps // thin)}
@@ -246,8 +289,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "C2: submmSED two-component greybody (submmModel2_normalized), "
-                               "%d synthetic sources x %d chains per GPU, 8 bands, FP64, doBlock" % (S, C),
+        "config": {"workload": "%s: submmSED two-component greybody (submmModel2_normalized), "
+                               "%d synthetic sources x %d chains per GPU (%d chains per source over "
+                               "the %d GPUs), 8 bands, FP64, doBlock" % (config, S, C, C * world, world),
                    "sources": S, "chains_per_source_per_gpu": C, "mh_steps_per_launch": inner,
                    "layout": "chain-sharded, R-hat all-reduce per step" if world > 1 else "single GPU",
                    "adapt_steps": args.adapt},
@@ -260,7 +304,13 @@ def main():
                              "per launch; traffic = HBM bytes per launch from rocprofv3 PMC "
                              "(profiles/r1_bench_summary.txt), ~1% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
+        # fraction of sources whose worst parameter has R-hat < 1.1 (reference formula,
+        # convergence.py:77-85) after adapt + warmup + timed steps
+        "rhat_lt_1p1_frac": float((torch.nan_to_num(rhat, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
+        "rhat_allreduce_bytes": 3 * 6 * 8 * S if world > 1 else 0,
     }
+    if args.dump_rhat and rank == 0:
+        np.save(args.dump_rhat, rhat.cpu().numpy())
     out.update(ess_out)
     out.update(inc_out)
     if rank == 0 and cpu is not None:
