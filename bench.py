@@ -137,6 +137,8 @@ def main():
                     help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
     ap.add_argument("--incremental-steps", type=int, default=3,
                     help="extra launches with the opt-in incremental sampler (0 = skip)")
+    ap.add_argument("--corr-steps", type=int, default=10000,
+                    help="MH steps of the correlated-proposal ESS/s measurement (one GPU only); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     args = ap.parse_args()
@@ -271,6 +273,43 @@ def main():
                                "estimator on the device, %d chains x %d thinned rows per source per "
                                "GPU) / wall time of that run incl. the estimator" % (C, args.ess_steps // thin)}
 
+    # Correlated proposals (newMCMC's Cholesky factor of the chain covariance, Proposal.py:150-154)
+    # in the fused kernel's extended instantiation: mixing per second beside the production
+    # configuration (driver.py:173-175 runs noCorrelations=True, which is what `value` measures)
+    corr_out = {}
+    if args.corr_steps > 0 and world == 1:
+        eng.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
+                            randomize_start=True, track_cov=True)
+        if eng.mh_fused_active:
+            eng.mh_run(2000)
+            eng.mh_adapt_corr(no_correlations=True)
+            eng.mh_run(2000)
+            for n in (1000, 3000):
+                eng.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
+                eng.mh_run(n)
+            eng.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
+            eng.mh_track_cov(False)
+            rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+            thin = max(1, args.corr_steps // rows)
+            eng.mh_run(100, thin=1)
+            barrier()
+            t3 = time.perf_counter()
+            eng.mh_run(args.corr_steps, thin=thin)
+            k_corr = eng.last_kernel_ms
+            ess_c = eng.mh_ess()
+            barrier()
+            t_corr = time.perf_counter() - t3
+            rh = torch.from_numpy(eng.rhat())
+            em = np.nanmin(np.where(np.isfinite(ess_c), ess_c, np.nan), axis=1)
+            corr_out = {"correlated_proposals": {
+                "ess_per_sec": float(np.nansum(em)) / t_corr, "ess_median_per_source": float(np.nanmedian(em)),
+                "steps": args.corr_steps, "evals_per_s": float(S) * C * args.corr_steps / (k_corr * 1e-3),
+                "kernel": "k_mh_run<M2N, fast, extended>", "kernel_ms": k_corr,
+                "rhat_median": float(torch.nanmedian(rh).item()),
+                "rhat_lt_1p1_frac": float((torch.nan_to_num(rh, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
+                "note": "after 8000 adaptation steps (two uncorrelated and two correlated stages, fac 0.6); "
+                        "R-hat over the moments of the measured stage incl. its 100 trace-allocation steps"}}
+
     evals_per_launch = float(S) * C * inner                   # per GPU
     total_evals = evals_per_launch * args.steps * world
     value = total_evals / elapsed
@@ -313,6 +352,7 @@ def main():
         np.save(args.dump_rhat, rhat.cpu().numpy())
     out.update(ess_out)
     out.update(inc_out)
+    out.update(corr_out)
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:

@@ -319,8 +319,11 @@ int mi355_mh_init_problem(mi355_ctx* ctx, int32_t problem, int32_t C, const doub
  * sets need at most 11 marginalisation points per chain (no marginalisation, analytic, or the
  * 11-point calibration or beam grid) runs mi355_mh_run as ONE kernel launch: every MH step of
  * MCMC.py:225-286 - proposal of any mode, band powers, MFMA quadratic form, marginalisation,
- * accept, moments - inside it, chain state in LDS.  Same draws, same arithmetic, same chains as
- * the step-wise launches, bit for bit.  on=0 forces the step-wise launches (on by default).
+ * accept, moments - inside it, chain state on chip.  A SED problem on a catalogue that passed the
+ * fast-path check of mi355_sed_load runs in the fused SED kernel of mi355_mh_init, extended by the
+ * correlated and rotated proposals (Proposal.py:145-154) and the co-moments.  Same draws, same
+ * arithmetic, same chains as the step-wise launches, bit for bit.  on=0 forces the step-wise
+ * launches (on by default).
  * mi355_mh_fused_active: 1 if the next mi355_mh_run of this context takes the one-launch path. */
 int mi355_mh_set_fused(mi355_ctx* ctx, int32_t on);
 int mi355_mh_fused_active(mi355_ctx* ctx);
@@ -337,6 +340,10 @@ int mi355_mh_adapt_corr(mi355_ctx* ctx, double fac, int32_t random_restart, int3
 /* covar(burn=1) of every chain (MCMC.py:310-340) from the running co-moments: host [S,C,P,P];
  * normalized=1 divides by stdev_i*stdev_j. */
 int mi355_mh_covar(mi355_ctx* ctx, double* cov, int32_t normalized);
+/* Pause / resume the running co-moments of a sampler started with track_cov=1: a production stage
+ * that will not be adapted from need not pay for them (P(P+1)/2 read-modify-writes per chain and
+ * step).  mi355_mh_covar and correlated restarts need them on for every step of the stage. */
+int mi355_mh_track_cov(mi355_ctx* ctx, int32_t on);
 /* prop.sqrtMatrix of every chain: host [S,C,P,P]. */
 int mi355_mh_get_sqrt_matrix(mi355_ctx* ctx, double* L);
 /* 0 uncorrelated, 1 Cholesky-correlated, 2 rotated */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi355_mh_init_problem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32,
                                         c_double_p, C.c_int32, c_int32_p, C.c_int32, C.c_int32,
                                         C.c_int32]),
+    "mi355_mh_track_cov": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi355_mh_set_fused": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi355_mh_fused_active": (C.c_int, [C.c_void_p]),
     "mi355_mh_set_sqrt_matrix": (C.c_int, [C.c_void_p, c_double_p, C.c_int32, C.c_int32]),

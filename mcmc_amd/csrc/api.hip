@@ -149,7 +149,14 @@ struct LaunchRun {
         return 0;
       }
     }
-    if (c->kc.fast_ok != 0.0)
+    if (a.mode != 0 || a.comom != nullptr) {
+      // extended sampler: correlated / rotated proposals, co-moments (sed_mh_fused_ok checked it fits)
+      constexpr int ntri = ModelTraits<M>::P * (ModelTraits<M>::P + 1) / 2;
+      const size_t lds_ext = lds + static_cast<size_t>(ntri) * bs * sizeof(double);
+      MI355_REQUIRE(c->kc.fast_ok != 0.0 && lds_ext <= kLdsLimit,
+                    "the extended fused sampler does not serve this catalogue (step-wise engine only)");
+      hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+    } else if (c->kc.fast_ok != 0.0)
       hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
     else
       hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
@@ -569,10 +576,36 @@ int mi355_mh_init(mi355_ctx* c, int32_t C, const double* theta0, int32_t theta0_
   return 0;
 }
 
+}  // extern "C"
+
+namespace mi355 {
+// Whether chains started by mi355_mh_init_problem on the SED catalogue can run in the fused kernel
+// (its extended instantiation): clamp-free fast path, parameters within the block-mask tables,
+// LDS for the band tables plus the per-lane sqrt matrix.
+bool sed_mh_fused_ok(const mi355_ctx* c) {
+  if (!c || !c->sed_loaded || c->kc.fast_ok == 0.0 || c->P > kMaxParam) return false;
+  size_t lds = 0;
+  const int bs = pick_block(c->C, c->nbm, c->S, &lds);
+  return bs > 0 && lds + static_cast<size_t>(c->P * (c->P + 1) / 2) * bs * sizeof(double) <= kLdsLimit;
+}
+}  // namespace mi355
+
+extern "C" {
+
 int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_normals,
                  const double* inj_uniforms) {
   MI355_REQUIRE(c && c->mh_ready, "mi355_mh_run: chains not initialised (call mi355_mh_init)");
   if (gmh_active(c)) return gmh_run(c, nsteps, thin, inj_normals, inj_uniforms);
+  return sed_mh_run(c, nsteps, thin, inj_normals, inj_uniforms, 0, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace mi355 {
+// MC_append for every chain in one launch of the fused SED kernel; mode / L / comom: the proposal
+// and co-moment state of chains the step-wise engine started (0 / null for mi355_mh_init chains).
+int sed_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_normals,
+               const double* inj_uniforms, int mode, const double* L, double* comom) {
   MI355_REQUIRE(nsteps >= 0 && thin >= 0, "negative nsteps/thin");
   MI355_REQUIRE((inj_normals == nullptr) == (inj_uniforms == nullptr),
                 "inj_normals and inj_uniforms must be given together");
@@ -582,6 +615,9 @@ int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n
   MhArgs a = base_args(c);
   a.nsteps = nsteps;
   a.thin = thin;
+  a.mode = mode;
+  a.L = L;
+  a.comom = comom;
   if (inj_normals) {
     const size_t nn = static_cast<size_t>(nsteps) * c->N * P, nu = static_cast<size_t>(nsteps) * c->N;
     if (c->scratch_a.alloc(nn) || c->scratch_b.alloc(nu)) return -2;
@@ -610,6 +646,9 @@ int mi355_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n
   MI355_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
+}  // namespace mi355
+
+extern "C" {
 
 int mi355_mh_set_incremental(mi355_ctx* c, int32_t on) {
   MI355_REQUIRE(c, "null context");

@@ -175,6 +175,10 @@ inline void mh_invalidate(mi355_ctx* c) {
   gmh_deactivate(c);
 }
 int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, const double* inj_u);
+// fused SED kernel (api.hip), also the one-launch path of step-wise SED chains
+bool sed_mh_fused_ok(const mi355_ctx* c);
+int sed_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_normals,
+               const double* inj_uniforms, int mode, const double* L, double* comom);
 int gmh_adapt(mi355_ctx* c, double fac, int random_restart, int no_correlations, int rotate,
               int do_block);
 }  // namespace mi355

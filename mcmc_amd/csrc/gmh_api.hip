@@ -14,11 +14,13 @@ struct GmhState {
   bool active = false;
   GmhProblem pb{};
   int mode = GMH_UNCORR;
-  bool track_cov = false;
+  bool track_cov = false;           // co-moment buffers exist (mi355_mh_init_problem track_cov=1)
+  bool cov_on = false;              // ... and runs update them (mi355_mh_track_cov)
+  int64_t cov_nsamp = 0;            // samples of the current stage the co-moments hold
   int nblock_table = 0;             // blocks of the table given at init (doBlock can be toggled)
   DevBuf<double> theta_new, prior_new, lnl_new, zbuf, comom, L, stage_a, stage_b;
   DevBuf<int32_t> block_of, rank_in_block;
-  std::vector<int32_t> h_block_of;
+  std::vector<int32_t> h_block_of, h_rank;
   int maxblk = 1;
   // hipGraph replay of free-running steps (no trace, no injection)
   DevBuf<GmhDyn> dyn;
@@ -72,7 +74,7 @@ static GmhArgs base_args(mi355_ctx* c) {
   a.lnPr = c->lnPr.p;
   a.mean = c->mean.p;
   a.m2 = c->m2.p;
-  a.comom = g->track_cov ? g->comom.p : nullptr;
+  a.comom = g->cov_on ? g->comom.p : nullptr;
   a.naccept = c->naccept.p;
   a.accept = c->accept.p;
   a.flags = c->flags.p;
@@ -99,6 +101,34 @@ static void set_npn(mi355_ctx* c) {
   const int P = g->pb.P;
   if (g->mode == GMH_CORR || c->nblock == 0) c->npn = (P + 1) & ~1;
   else c->npn = g->maxblk == 1 ? 1 : ((g->maxblk + 1) & ~1);
+}
+
+// Block tables of the fused SED kernel (bit masks in the context) from the engine's own, for the
+// current doBlock setting; problems with more parameters than the masks hold never run fused.
+static void sync_block_masks(mi355_ctx* c) {
+  GmhState* g = c->gmh;
+  const int P = g->pb.P;
+  if (P > kMaxParam) return;
+  for (int b = 0; b < kMaxParam; ++b) c->blockmask[b] = 0;
+  for (int i = 0; i < kMaxParam; ++i) c->rank_in_block[i] = 0;
+  for (int i = 0; i < P; ++i) {
+    if (c->nblock > 0) {
+      const int b = g->h_block_of[i];
+      if (b >= 0 && b < kMaxParam) c->blockmask[b] |= 1u << i;
+      c->rank_in_block[i] = g->h_rank[i];
+    } else {
+      c->rank_in_block[i] = i;
+    }
+  }
+}
+
+// one-launch path of the running sampler: 1 binnedCl kernel, 2 SED kernel, 0 launch per step
+static int fused_kind(mi355_ctx* c) {
+  GmhState* g = c->gmh;
+  if (!c->mh_fused) return 0;
+  if (g->pb.kind == GMH_CL && cl_mh_fused_nw(c, g->pb.P, c->nblock, c->npn) > 0) return 1;
+  if (g->pb.kind == GMH_SED && sed_mh_fused_ok(c)) return 2;
+  return 0;
 }
 
 static int check_flags(mi355_ctx* c, const char* who) {
@@ -135,6 +165,7 @@ static int finish_start(mi355_ctx* c, GmhArgs& a, const char* who) {
   c->stage_step = 0;
   c->nsamp = 0;
   c->nkeep = 0;
+  c->gmh->cov_nsamp = 0;
   return check_flags(c, who);
 }
 
@@ -207,6 +238,14 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
   MI355_HIP(hipSetDevice(c->device));
   const int P = g->pb.P;
   const int64_t N = c->N;
+  if (g->cov_on) g->cov_nsamp += nsteps;
+  if (fused_kind(c) == 2) {
+    // SED: the fused kernel's extended instantiation (sed_kernels.hpp) - every proposal mode and
+    // the co-moments at the one-launch rate; uploads, trace and counters are sed_mh_run's
+    sync_block_masks(c);
+    return sed_mh_run(c, nsteps, thin, inj_n, inj_u, g->mode, g->mode != GMH_UNCORR ? g->L.p : nullptr,
+                      g->cov_on ? g->comom.p : nullptr);
+  }
   if (inj_n) {
     const size_t nn = static_cast<size_t>(nsteps) * N * P, nu = static_cast<size_t>(nsteps) * N;
     if (g->stage_a.alloc(nn) || g->stage_b.alloc(nu)) return -2;
@@ -218,7 +257,8 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     const size_t rows = static_cast<size_t>(c->nkeep) * N;
     if (c->tr_theta.alloc(rows * P) || c->tr_lnPr.alloc(rows) || c->tr_acc.alloc(rows)) return -2;
   }
-  if (g->pb.kind == GMH_CL && c->mh_fused && cl_mh_fused_nw(c, P, c->nblock, c->npn) > 0) {
+  const int fused = fused_kind(c);
+  if (fused == 1) {
     // binnedCl: the whole run in one launch of the fused kernel (cl_mh_kernels.hpp)
     GmhArgs a = base_args(c);
     a.blk = c->nblock ? static_cast<int>(c->stage_step % c->nblock) : 0;
@@ -299,6 +339,10 @@ int gmh_adapt(mi355_ctx* c, double fac, int random_restart, int no_correlations,
   MI355_REQUIRE(!corr || g->track_cov,
                 "correlated / rotated proposals need the chain covariance: pass track_cov=1 to "
                 "mi355_mh_init_problem");
+  MI355_REQUIRE(!corr || g->cov_nsamp == c->nsamp,
+                "the co-moments hold %lld of the stage's %lld samples (mi355_mh_track_cov was off for "
+                "part of it): no covariance to adapt from", static_cast<long long>(g->cov_nsamp),
+                static_cast<long long>(c->nsamp));
   if (do_block >= 0) {
     MI355_REQUIRE(do_block == 0 || g->nblock_table > 0,
                   "doBlock=True needs the parameter blocks given to mi355_mh_init_problem");
@@ -374,6 +418,7 @@ int mi355_mh_init_problem(mi355_ctx* c, int32_t problem, int32_t C, const double
   g->pb = pb;
   g->mode = GMH_UNCORR;
   g->track_cov = track_cov != 0;
+  g->cov_on = g->track_cov;
   c->mhP = P;
   c->mhS = units;
   c->C = C;
@@ -382,7 +427,9 @@ int mi355_mh_init_problem(mi355_ctx* c, int32_t problem, int32_t C, const double
   g->nblock_table = nblock;
   // block tables; a parameter with block id -1 (or beyond the table) belongs to no block
   g->h_block_of.assign(static_cast<size_t>(P), -1);
-  std::vector<int32_t> rank(static_cast<size_t>(P), 0), count(static_cast<size_t>(P) + 1, 0);
+  std::vector<int32_t>& rank = g->h_rank;
+  rank.assign(static_cast<size_t>(P), 0);
+  std::vector<int32_t> count(static_cast<size_t>(P) + 1, 0);
   g->maxblk = 1;
   if (nblock > 0) {
     for (int i = 0; i < P; ++i) {
@@ -495,6 +542,9 @@ static int gather(mi355_ctx* c, const double* dev, double scale, int sym, const 
 int mi355_mh_covar(mi355_ctx* c, double* cov, int32_t normalized) {
   MI355_REQUIRE(gmh_active(c) && c->mh_ready && cov, "mi355_mh_covar: no step-wise sampler");
   MI355_REQUIRE(c->gmh->track_cov, "mi355_mh_covar: the sampler was started with track_cov=0");
+  MI355_REQUIRE(c->gmh->cov_nsamp == c->nsamp, "mi355_mh_covar: the co-moments hold %lld of the stage's "
+                "%lld samples (mi355_mh_track_cov was off for part of it)",
+                static_cast<long long>(c->gmh->cov_nsamp), static_cast<long long>(c->nsamp));
   MI355_REQUIRE(c->nsamp > 0, "mi355_mh_covar: no samples accumulated yet");
   MI355_HIP(hipSetDevice(c->device));
   const double rn = 1.0 / static_cast<double>(c->nsamp);
@@ -510,6 +560,14 @@ int mi355_mh_get_sqrt_matrix(mi355_ctx* c, double* L) {
 
 int32_t mi355_mh_proposal_mode(mi355_ctx* c) { return gmh_active(c) ? c->gmh->mode : 0; }
 
+int mi355_mh_track_cov(mi355_ctx* c, int32_t on) {
+  MI355_REQUIRE(gmh_active(c) && c->mh_ready, "mi355_mh_track_cov: no step-wise sampler");
+  MI355_REQUIRE(!on || c->gmh->track_cov, "mi355_mh_track_cov: the sampler was started with track_cov=0");
+  if ((on != 0) != c->gmh->cov_on) c->gmh->version += 1;   // a captured graph has the old setting baked in
+  c->gmh->cov_on = on != 0;
+  return 0;
+}
+
 int mi355_mh_set_fused(mi355_ctx* c, int32_t on) {
   MI355_REQUIRE(c, "null context");
   c->mh_fused = on != 0;
@@ -517,8 +575,8 @@ int mi355_mh_set_fused(mi355_ctx* c, int32_t on) {
 }
 
 int mi355_mh_fused_active(mi355_ctx* c) {
-  if (!gmh_active(c) || !c->mh_ready || !c->mh_fused) return 0;
-  return (c->gmh->pb.kind == GMH_CL && cl_mh_fused_nw(c, c->gmh->pb.P, c->nblock, c->npn) > 0) ? 1 : 0;
+  if (!gmh_active(c) || !c->mh_ready) return 0;
+  return fused_kind(c) ? 1 : 0;
 }
 
 }  // extern "C"

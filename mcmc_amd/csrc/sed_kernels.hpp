@@ -50,6 +50,11 @@ struct MhArgs {
   int adapt;              // 1: centre and sigma come from the chain's own moments
   double fac;
   int random_restart;
+  // extended sampler (k_mh_run<.., EXT = true>): the proposals of Proposal.py:145-154 and the
+  // running co-moments of covar() (MCMC.py:310-340), for chains started by mi355_mh_init_problem
+  int mode;               // 0 uncorrelated, 1 Cholesky-correlated, 2 rotated (GmhMode)
+  const double* L;        // [P][P][N] sqrtMatrix per chain (modes 1, 2)
+  double* comom;          // [P][P][N], lower triangle used; null: covariance not tracked
 };
 
 constexpr int kStartMaxTries = 100000;
@@ -238,9 +243,20 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 #ifndef MI355_ABL
 #define MI355_ABL 0       // timing ablations of tools/ablate.sh (never set in the product build)
 #endif
-template <int MODEL, bool FAST>
+// EXT: the same sampler with everything the step-wise engine (gmh_kernels.hpp) adds - Cholesky-
+// correlated proposals (Proposal.py:150-154: offset = (L z) sigma over the block, P normals per
+// step), rotated proposals (:145-148: offset = sum over the block's members j of L[:, j] z_j, every
+// parameter moves) and the running co-moments newMCMC's covariance needs (MCMC.py:310-340) - so
+// that correlated stages run at the fused kernel's rate (a step of the step-wise engine is three
+// launches).  The chain's lower-triangular L sits in the lane's column of an LDS array
+// [P(P+1)/2][blockDim] behind the band tables; the co-moments stay in HBM (read-modify-write every
+// step: only adaptation stages track them).  Same draws, same arithmetic as k_gmh_propose /
+// k_gmh_accept: tests/test_gmh_gpu.py holds the two to identical chains.  A separate instantiation,
+// so the uncorrelated production kernel keeps its registers.
+template <int MODEL, bool FAST, bool EXT = false>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   constexpr int P = ModelTraits<MODEL>::P;
+  constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
   const int stride = kBandFields * a.nbm;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
@@ -275,6 +291,17 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   }
   double lnPr = a.lnPr[n];
   uint32_t nacc = a.naccept[n];
+  // EXT: this chain's sqrt matrix, lower triangle row by row, in the lane's LDS column
+  double* Ll = smem + static_cast<size_t>(nsrc) * stride + threadIdx.x;
+  if constexpr (EXT) {
+    if (a.mode != 0) {
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          Ll[(i * (i + 1) / 2 + j) * blockDim.x] = a.L[(static_cast<int64_t>(i) * P + j) * a.N + n];
+    }
+  }
 
   const bool inject = a.inj_n != nullptr;
   const uint32_t allmask = (1u << P) - 1u;
@@ -290,7 +317,43 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 #pragma unroll
     for (int i = 0; i < P; ++i) nw[i] = th[i];
     double u;
-    if (inject) {
+    if (EXT && a.mode != 0) {
+      // z_j of the step: correlated - normal(step npn + j) for every j; rotated - normal(step npn +
+      // rank_j) for the members j of the block (injected rows: element j / element rank_j)
+      double z[P];
+      if (inject) {
+        const double* zn = a.inj_n + (t * a.N + n) * P;
+#pragma unroll
+        for (int j = 0; j < P; ++j) z[j] = zn[a.mode == 1 ? j : a.rank_in_block[j]];
+        u = a.inj_u[t * a.N + n];
+      } else {
+        if (a.mode == 1) {                                 // npn is even: whole Philox pairs
+#pragma unroll
+          for (int j = 0; j < P; j += 2) {
+            double p0, p1;
+            philox_normal2(a.seed, RNG_NORMAL, n, (step * a.npn + j) >> 1, p0, p1);
+            z[j] = p0;
+            if (j + 1 < P) z[j + 1] = p1;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < P; ++j)
+            z[j] = ((mask >> j) & 1u) ? philox_normal(a.seed, RNG_NORMAL, n, step * a.npn + a.rank_in_block[j])
+                                      : 0.0;
+        }
+        u = philox_uniform(a.seed, RNG_UNIFORM, n, step);
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        double sum = 0.0;                                  // row i of L times z, j ascending
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          const double lij = Ll[(i * (i + 1) / 2 + j) * blockDim.x];
+          if (a.mode == 1 || ((mask >> j) & 1u)) sum += lij * z[j];
+        }
+        if (a.mode == 2 || ((mask >> i) & 1u)) nw[i] += sum * sg[i];   // Proposal.py:145-159
+      }
+    } else if (inject) {
       const double* zn = a.inj_n + (t * a.N + n) * P;
 #pragma unroll
       for (int i = 0; i < P; ++i)
@@ -359,11 +422,30 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     // running ddof=0 moments over every appended sample (mean/stdev with burn=1, :290-307)
 #if MI355_ABL != 1
     const double rn = rcp_nr(static_cast<double>(a.nsamp0 + t + 1));   // 1/n to 2^-50
+    double dl[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const double dlt = th[i] - mu[i];
+      dl[i] = dlt;
       mu[i] = fma(dlt, rn, mu[i]);
       m2[i] = fma(dlt, th[i] - mu[i], m2[i]);
+    }
+    if constexpr (EXT) {
+      if (a.comom != nullptr) {                            // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
+        const double cf = 1.0 - rn;
+        double cur[NTRI];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j)
+            cur[i * (i + 1) / 2 + j] = a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j)
+            a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n] =
+                cur[i * (i + 1) / 2 + j] + cf * dl[i] * dl[j];
+      }
     }
 #endif
     if (a.thin > 0) {

@@ -278,6 +278,10 @@ class Engine:
         the two-component models in single-parameter block mode"""
         check(self.lib.mi355_mh_set_incremental(self._h, 1 if on else 0))
 
+    def mh_track_cov(self, on=True):
+        """pause / resume the running co-moments of a sampler started with track_cov=True"""
+        check(self.lib.mi355_mh_track_cov(self._h, 1 if on else 0))
+
     def mh_set_fused(self, on=True):
         """one-launch runs of step-wise problems where a fused kernel exists (binnedCl); on by
         default, off forces the launch-per-step engine (mi355_mh_set_fused)"""

@@ -156,20 +156,24 @@ def test_sed_stepwise_equals_fused_kernel():
     assert np.array_equal(ar, br)
 
 
-def test_sed_reference_correlated_stage():
+@pytest.mark.parametrize("fused", [True, False])
+def test_sed_reference_correlated_stage(fused):
     """newMCMC(noCorrelations=False) + 300 Cholesky-correlated steps of the reference's own
-    two-component chain (sed_g3 'm2n_block'), draw for draw."""
+    two-component chain (sed_g3 'm2n_block'), draw for draw - through the fused SED kernel's
+    extended instantiation and through the launch-per-step engine."""
     from mcmc_amd import Engine
     g2, g3 = load("sed_g2.npz"), load("sed_g3.npz")
     name = "m2n_block"
     di = int(g3[name + "__dataset"])
     nbd = int(g2["nb"][di])
     with Engine() as eng:
+        eng.mh_set_fused(fused)
         eng.sed_load("M2N", g2["nb"][di:di + 1], g2["nu"][di:di + 1], g2["d"][di:di + 1],
                      g2["sig"][di:di + 1])
         ref_s = g3[name + "__corr_samples"]
         eng.mh_init_problem("sed", 1, ref_s[0], g3[name + "__new_sigmas"], param_blocks=np.arange(6),
                             randomize_start=False)
+        assert eng.mh_fused_active == fused
         eng.mh_set_sqrt_matrix(g3[name + "__new_sqrt"], rotate=False)
         k0 = int(g3[name + "__new_kend"])
         zn = g3[name + "__all_normals"][k0:k0 + 300, None, :]
@@ -334,3 +338,60 @@ def test_graph_replay_survives_scratch_regrowth(kind):
             res.append(eng.mh_moments())
     for key in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
         assert np.array_equal(res[0][key], res[1][key]), key
+
+
+@pytest.mark.parametrize("model,mode", [("M2N", "uncorr_block"), ("M2N", "corr_all"), ("M2N", "corr_block"),
+                                        ("M2N", "rotate_block"), ("M1N_LOGA", "corr_all"),
+                                        ("THICK", "rotate_block")])
+def test_sed_fused_extended_kernel_equals_stepwise_engine(model, mode):
+    """Chains started by mi355_mh_init_problem on a SED catalogue: the fused kernel's extended
+    instantiation (correlated / rotated proposals, co-moments; one launch per run) against the
+    launch-per-step engine - same draws, same arithmetic, identical chains, covariance, adapted
+    widths and sqrt matrices; free-running and with injected draws."""
+    from mcmc_amd import Engine, synth
+    S, C = 5, 37
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=3)
+    nb = np.array([8, 6, 8, 7, 8], np.int32)
+    P = {"M2N": 6, "M1N_LOGA": 3, "THICK": 4}[model]
+    start = {"M2N": synth.M2N_START, "M1N_LOGA": [0.0, 2.0, 10.0], "THICK": [1.0, 2.0, 10.0, 1.0]}[model]
+    sg0 = {"M2N": synth.M2N_PROP_SIGMAS, "M1N_LOGA": [0.5, 0.5, 3.0], "THICK": [0.25, 0.5, 3.0, 0.3]}[model]
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    block = mode != "corr_all"
+    zn, zu = rng.standard_normal((25, S * C, P)), rng.uniform(size=(25, S * C))
+    res = []
+    for fused in (True, False):
+        out = {}
+        with Engine(seed=99) as eng:
+            eng.mh_set_fused(fused)
+            eng.sed_load(model, nb, nu, d, sig)
+            eng.mh_init_problem("sed", C, start, sg0, param_blocks=np.arange(P) if block else None,
+                                randomize_start=True, track_cov=True)
+            assert eng.mh_fused_active == fused
+            if mode != "uncorr_block":
+                eng.mh_set_sqrt_matrix(L, rotate=(mode == "rotate_block"))
+            eng.mh_run(60, thin=1)
+            out["t1"] = eng.mh_trace()
+            eng.mh_run(45)
+            eng.mh_run(25, thin=5, inj_normals=zn, inj_uniforms=zu)
+            out["t2"] = eng.mh_trace()
+            out["mom"] = eng.mh_moments()
+            out["cov"] = eng.mh_covar(normalized=False)
+            eng.mh_adapt_corr(no_correlations=False, rotate=(mode == "rotate_block"),
+                              do_block=block)
+            out["sig"] = eng.mh_sigmas()
+            out["L"] = eng.mh_sqrt_matrix()
+            eng.mh_run(50)
+            out["mom2"] = eng.mh_moments()
+            out["rhat"] = eng.rhat()
+        res.append(out)
+    a, b = res
+    for k in a:
+        x, y = a[k], b[k]
+        items = list(x.items()) if isinstance(x, dict) else list(enumerate(x)) if isinstance(x, tuple) else [(0, x)]
+        for kk, u in items:
+            v = y[kk] if isinstance(y, (dict, tuple)) else y
+            assert np.array_equal(u, v, equal_nan=True), (k, kk)
