@@ -278,16 +278,16 @@ def results_table(records, irun, nodat=False):
     for k, obj in enumerate(records):
         covar = np.array(obj[0][2])[:, ix][ix]
         ML, meanL = obj[1][0], obj[1][2]
-        lap = 0.5 * np.linalg.det(covar) + npar * 0.5 * np.log(2 * np.pi)
+        hdet, norm = 0.5 * np.linalg.det(covar), npar * 0.5 * np.log(2 * np.pi)   # summed left to right
         tab[k]["name"] = obj[2]
         tab[k]["mean"] = np.array(obj[0][0])[ix]
         tab[k]["sig"] = np.array(obj[0][1])[ix]
         tab[k]["covar"] = covar
         tab[k]["ML"] = ML
-        tab[k]["ev"] = ML + lap
+        tab[k]["ev"] = ML + hdet + norm
         tab[k]["MLpar"] = np.asarray(obj[1][1])[ix]
         tab[k]["MeanL"] = meanL
-        tab[k]["evMean"] = meanL + lap
+        tab[k]["evMean"] = meanL + hdet + norm
         tab[k]["dlnLike"] = ML - meanL
         tab[k]["z"] = obj[3]
         if ndat > 0:
@@ -308,21 +308,25 @@ def postprocess(runs, nodat=False):
     return out
 
 
-def writeTab(ret, fname, names=None, nodat=False):
+def writeTab(ret, fname, names=None, nodat=False, plain=False):
     """One text table per results table, columns and "%21s" cells as driver.py:478-534: Name, z,
     ML / mean / sigma of every parameter, dlnLike, evidence1, evidence2, [flux k, sigflux k ...],
-    greybody flux k ..., ML_chi2."""
+    greybody flux k ..., ML_chi2.
+
+    By default the file is byte for byte what the reference writes under Python 3
+    (tests/golden/writetab_g11.json): its table is one bytes array (names 'S21' stacked with the
+    numbers), so every cell prints as b'...'; numbers are NumPy's shortest round-trip text cut to
+    32 characters; and with nodat=True only the HEADER drops the flux / sigflux names - the rows keep
+    whatever the table's 'dat' field holds (nothing for tables made with nodat=True).  plain=True
+    writes the same layout with bare cells, which is what readtab() parses."""
     anames = ret["name"] if names is None else np.asarray(names)
     nn = ret.shape[0]
     npar = ret["MLpar"].shape[1]
     ndat = 0 if nodat else ret["dat"].shape[1]
     nt = ret["flux"].shape[1]
-    cols = [ret["z"].reshape(nn, 1), ret["MLpar"], ret["mean"], ret["sig"], ret["dlnLike"].reshape(nn, 1),
-            ret["ev"].reshape(nn, 1), ret["evMean"].reshape(nn, 1)]
-    if not nodat:
-        cols.append(ret["dat"].reshape(nn, -1))
-    cols += [ret["flux"].reshape(nn, -1), ret["ML_chi2"].reshape(nn, 1)]
-    nums = np.hstack(cols)
+    nums = np.hstack([ret["z"].reshape(nn, 1), ret["MLpar"], ret["mean"], ret["sig"],
+                      ret["dlnLike"].reshape(nn, 1), ret["ev"].reshape(nn, 1), ret["evMean"].reshape(nn, 1),
+                      ret["dat"].reshape(nn, -1), ret["flux"].reshape(nn, -1), ret["ML_chi2"].reshape(nn, 1)])
     hdr = ["Name", "z"]
     hdr += ["ML param %d" % k for k in range(npar)]
     hdr += ["Mean param %d" % k for k in range(npar)]
@@ -332,11 +336,11 @@ def writeTab(ret, fname, names=None, nodat=False):
         hdr += ["flux %d" % k, "sigflux %d" % k]
     hdr += ["greybody flux %d" % k for k in range(nt)]
     hdr.append("ML_chi2")
-    assert len(hdr) == nums.shape[1] + 1
+    cells = np.hstack([np.asarray(anames).astype("S21").astype("S32").reshape(nn, 1), nums.astype("S32")])
     with open(fname, "w") as f:
         f.write(("%21s " * len(hdr)) % tuple(hdr) + "\n")
-        for name, row in zip(anames, nums):
-            f.write(" ".join(["%21s" % name] + ["%21s" % repr(float(v)) for v in row]) + "\n")
+        for row in cells:
+            f.write(" ".join("%21s" % (c.decode() if plain else c) for c in row) + "\n")
 
 
 def writeTabAll(ret123, fbase, ext=".npy", nodat=False):

@@ -1121,9 +1121,66 @@ def golden_beamfuncs(R):
     print("wrote beamfuncs_g10.json")
 
 
+def golden_writetab(R):
+    """G11: the reference's results tables - postprocess() (driver.py:345-460) on checkpoint files
+    written here from seeded stub records, then writeTab() (:478-534) - as data: the records, the
+    fields of the structured arrays and the text files byte for byte.  Shims (no arithmetic): an
+    empty `getdist` module so that driver.py imports (:47), and the module's `open` reads the
+    checkpoints in binary mode (its text-mode open(fname) predates Python 3's pickle)."""
+    import builtins
+    import json
+    import pickle
+    import tempfile
+    sys.modules.setdefault("getdist", types.ModuleType("getdist"))
+    drv = importlib.import_module("MCMC.submmSED.driver")
+    drv.open = lambda fn, mode="rb": builtins.open(fn, mode if "w" in mode else "rb")
+    rng = np.random.default_rng(77)
+    full = 6                                             # every run's chains carry the flat 6 (or fewer) params
+    shapes = {0: (6, 2, 3), 1: (3, 1, 4), 3: (6, 2, 2), 4: (4, 1, 3)}   # run -> (P of the chain, nt, nobj)
+    ndat = 5
+    out = {"runs": {}, "ndat": ndat}
+    with tempfile.TemporaryDirectory() as tmp:
+        for irun, (P, nt, nobj) in shapes.items():
+            recs = []
+            for k in range(nobj):
+                A = rng.standard_normal((P, P))
+                cov = A @ A.T
+                sd = np.sqrt(np.diag(cov))
+                ML = float(rng.normal(-20, 5))
+                recs.append(((rng.normal(size=P), sd, cov / np.outer(sd, sd)),
+                             (ML, rng.normal(size=P), ML - abs(float(rng.normal()))),
+                             "F%05d+%04d(z=%5.3f)" % (1234 * k + irun, 77 * k, 0.013 * k), 0.013 * k,
+                             [(float(a), float(b)) for a, b in rng.uniform(0.1, 9, (ndat, 2))],
+                             rng.uniform(1, 2, nt), float(rng.uniform(1, 30))))
+            with builtins.open(os.path.join(tmp, "check%d.npy" % irun), "wb") as f:
+                pickle.dump(recs, f)
+            out["runs"][str(irun)] = {"records": [
+                {"mean": r[0][0].tolist(), "sig": r[0][1].tolist(), "ncov": r[0][2].tolist(), "ML": r[1][0],
+                 "MLpar": r[1][1].tolist(), "meanL": r[1][2], "name": r[2], "z": r[3], "dat": r[4],
+                 "flux": r[5].tolist(), "ML_chi2": r[6]} for r in recs]}
+        tabs = drv.postprocess(tmp + "/", check=True)
+        for irun, tab in enumerate(tabs):
+            if len(tab) == 0:
+                continue
+            e = out["runs"][str(irun)]
+            e["fields"] = {k: tab[k].tolist() for k in ("mean", "sig", "covar", "ML", "ev", "MLpar", "MeanL",
+                                                        "evMean", "dlnLike", "z", "dat", "flux", "ML_chi2")}
+            e["name"] = [n.decode() for n in tab["name"]]
+            for nodat in (False, True):
+                fn = os.path.join(tmp, "tab%d_%d.txt" % (irun, nodat))
+                drv.writeTab(tab, fn, nodat=nodat)
+                with builtins.open(fn) as f:
+                    e["text_nodat" if nodat else "text"] = f.read()
+    out["reference_sha256"] = hashlib.sha256(
+        builtins.open(os.path.join(REF, "MCMC/submmSED/driver.py"), "rb").read()).hexdigest()
+    with builtins.open(os.path.join(OUT, "writetab_g11.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("writetab_g11.json: runs", sorted(out["runs"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist", "beamfuncs"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist", "beamfuncs", "writetab"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -1139,6 +1196,8 @@ def main():
         golden_getdist(R)
     if "beamfuncs" in which:
         golden_beamfuncs(R)
+    if "writetab" in which:
+        golden_writetab(R)
 
 
 if __name__ == "__main__":

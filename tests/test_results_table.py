@@ -1,8 +1,13 @@
-"""Results tables of the catalogue driver (postprocess / writeTab, driver.py:345-534).
-Parity unpinned for the text layout: the reference's driver module cannot be imported here
-(getdist is absent, driver.py:47), so the format is restated from its source and checked for
-structure, the evidence formula and a round trip."""
+"""Results tables of the catalogue driver (postprocess / writeTab, driver.py:345-534) against the
+reference's own output: tests/golden/writetab_g11.json holds seeded stub records, the structured
+arrays the reference's postprocess() made of them and the text its writeTab() wrote (made by
+`oracle/make_golden.py writetab`, which imports the reference's driver with an empty `getdist`
+stub).  Fields bit for bit, files byte for byte."""
+import json
+import os
+
 import numpy as np
+import pytest
 
 from mcmc_amd.submmSED import driver as drv
 
@@ -23,6 +28,32 @@ def fake_records(n, P, ndat, nt, seed=0):
     return recs
 
 
+@pytest.fixture(scope="module")
+def g11():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "writetab_g11.json")) as f:
+        return json.load(f)
+
+
+def golden_records(run):
+    return [((np.array(r["mean"]), np.array(r["sig"]), np.array(r["ncov"])),
+             (r["ML"], np.array(r["MLpar"]), r["meanL"]), r["name"], r["z"],
+             [tuple(x) for x in r["dat"]], np.array(r["flux"]), r["ML_chi2"]) for r in run["records"]]
+
+
+@pytest.mark.parametrize("irun", [0, 1, 3, 4])
+def test_results_table_and_text_equal_the_reference(g11, irun, tmp_path):
+    run = g11["runs"][str(irun)]
+    tab = drv.results_table(golden_records(run), irun)
+    assert list(tab["name"]) == run["name"]
+    for k, want in run["fields"].items():
+        np.testing.assert_array_equal(tab[k], np.array(want), err_msg=k)
+    f = tmp_path / "tab.txt"
+    drv.writeTab(tab, str(f))
+    assert f.read_text() == run["text"]
+    drv.writeTab(tab, str(f), nodat=True)                  # the reference drops the names, not the columns
+    assert f.read_text() == run["text_nodat"]
+
+
 def test_results_table_columns_and_evidence():
     recs = fake_records(4, 6, 7, 2)
     tab = drv.results_table(recs, 0)                      # 2-component, beta fixed: A1 T1 A2 T2
@@ -33,8 +64,8 @@ def test_results_table_columns_and_evidence():
         np.testing.assert_array_equal(tab[k]["MLpar"], r[1][1][ix])
         cov = r[0][2][:, ix][ix]
         np.testing.assert_array_equal(tab[k]["covar"], cov)
-        lap = 0.5 * np.linalg.det(cov) + 4 * 0.5 * np.log(2 * np.pi)   # driver.py:436
-        assert tab[k]["ev"] == r[1][0] + lap and tab[k]["evMean"] == r[1][2] + lap
+        hdet, norm = 0.5 * np.linalg.det(cov), 4 * 0.5 * np.log(2 * np.pi)   # driver.py:436
+        assert tab[k]["ev"] == r[1][0] + hdet + norm and tab[k]["evMean"] == r[1][2] + hdet + norm
         assert tab[k]["dlnLike"] == r[1][0] - r[1][2]
         assert tab[k]["name"] == r[2][:21]
 
@@ -43,7 +74,7 @@ def test_writetab_layout_and_roundtrip(tmp_path):
     recs = fake_records(5, 3, 4, 1, seed=2)
     tab = drv.results_table(recs, 1)
     f = tmp_path / "tab1.txt"
-    drv.writeTab(tab, str(f))
+    drv.writeTab(tab, str(f), plain=True)
     lines = f.read_text().splitlines()
     assert len(lines) == 6
     ncol = 2 + 3 * 3 + 3 + 2 * 4 + 1 + 1
@@ -59,7 +90,7 @@ def test_writetab_layout_and_roundtrip(tmp_path):
                                r["dat"].ravel(), r["flux"], [r["ML_chi2"]]))
         np.testing.assert_array_equal(vals, want)         # repr() round-trips float64 exactly
     g = tmp_path / "nodat.txt"
-    drv.writeTab(drv.results_table(recs, 1, nodat=True), str(g), nodat=True)
+    drv.writeTab(drv.results_table(recs, 1, nodat=True), str(g), nodat=True, plain=True)
     assert len(g.read_text().splitlines()[1].split()) == ncol - 8
 
 
@@ -94,7 +125,7 @@ def test_readtab_reads_what_writetab_wrote(tmp_path, capsys):
     recs = fake_records(5, 6, 3, 2, seed=4)
     tab = drv.results_table(recs, 0)
     f = str(tmp_path / "t.txt")
-    drv.writeTab(tab, f)
+    drv.writeTab(tab, f, plain=True)
     got = readtab(f)
     out = capsys.readouterr().out
     npar = tab["MLpar"].shape[1]
