@@ -326,20 +326,23 @@ __device__ double sed_lnlike(const double* th, const Bands& B, const SedConsts& 
       m00 += g1w * g1; m01 += g1w * g2; m11 += g2w * g2;
       b0 += g1w * d;   b1 += g2w * d;
     }
-    // (F^T N^-1 F) z = F^T N^-1 d, 2x2 LU with partial pivoting       likelihood.py:49-74
-    double z0, z1;
-    if (fabs(m00) >= fabs(m01)) {
-      const double l = m01 / m00;
-      const double u11 = m11 - l * m01;
-      z1 = (b1 - l * b0) / u11;
-      z0 = (b0 - m01 * z1) / m00;
-      if (u11 == 0.0 || m00 == 0.0) z0 = z1 = __builtin_nan("");      // LinAlgError -> reject
-    } else {
-      const double l = m00 / m01;
-      const double u11 = m01 - l * m11;
-      z1 = (b0 - l * b1) / u11;
-      z0 = (b1 - m11 * z1) / m01;
-      if (u11 == 0.0) z0 = z1 = __builtin_nan("");
+    // (F^T N^-1 F) z = F^T N^-1 d as linalg.solve(..., sym_pos=True) does it (likelihood.py:63):
+    // Cholesky U^T U of the upper triangle, then the two triangular solves - in LAPACK / OpenBLAS
+    // operation order (reciprocal pivots, fused multiply-adds in the substitutions; oracle/refcpu.py
+    // matches the reference's fixture bit for bit with it).  Not positive definite = LinAlgError
+    // there = ZeroPosterior = the point is rejected: NaN here.
+    double z0 = __builtin_nan(""), z1 = z0;
+    if (m00 > 0.0) {
+      const double r00 = 1.0 / sqrt(m00);
+      const double u01 = m01 * r00;
+      const double d11 = m11 - u01 * u01;
+      if (d11 > 0.0) {
+        const double r11 = 1.0 / sqrt(d11);
+        const double y0 = b0 * r00;
+        const double y1 = fma(-u01, y0, b1) * r11;
+        z1 = y1 * r11;
+        z0 = fma(-u01, z1, y0) * r00;
+      }
     }
     if (derived) { derived[0] = z0; derived[1] = z1; }
     return 0.5 * (b0 * z0 + b1 * z1);

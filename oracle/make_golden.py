@@ -111,6 +111,17 @@ def golden_sed(R):
     sha = ref_tree_sha()
     rng = np.random.default_rng(1234)
 
+    import scipy.linalg as _sla
+
+    def solve_compat(a, b, overwrite_a=False, overwrite_b=False, sym_pos=False, **kw):
+        # sym_pos=True is assume_a="pos" in SciPy >= 1.11 (the same LAPACK Cholesky solve).  The
+        # overwrite hints are NOT passed on: with overwrite_b honoured LAPACK returns the solution
+        # in FNid itself, which likelihood.py:72-74 reads again as the right-hand side, and the
+        # class returns z.z/2 instead of its documented (FB)(BB)^-1(BF)/2 (recorded once below as
+        # lnl_5_overwrite_quirk; the build implements the documented formula).
+        return _sla.solve(a, b, assume_a="pos" if sym_pos else "gen", **kw)
+    like_mod.linalg = types.SimpleNamespace(solve=solve_compat, det=_sla.det, LinAlgError=_sla.LinAlgError)
+
     classes = [model.submmModel1_normalized, model.submmModel1_normalized_logA,
                model.submmModel2_normalized, model.submmModel2_normalized_logA,
                model.submmModel1, model.submmModel2,
@@ -219,19 +230,20 @@ def golden_sed(R):
             for t in range(NT):
                 with np.errstate(all="ignore"):
                     if mid == 5:
-                        # SEDLikelihood2.lnLike1 raises TypeError under SciPy>=1.11 (sym_pos kwarg,
-                        # likelihood.py:63); evaluate its formula with the same quadforms and
-                        # numpy.linalg.solve.  Flagged "restated" in DESIGN.md.
-                        L.setModel(th[t])
-                        mv, dd = L.model_vals[0], L.data[0]
-                        FNiF = dd.quadform(mv); FNid = dd.quadform(mv, dd.d)
+                        # SEDLikelihood2.lnLike1 itself (likelihood.py:35-74), with scipy.linalg.solve
+                        # seen through solve_compat below: the class passes sym_pos=True, which
+                        # SciPy >= 1.11 spells assume_a="pos" (same LAPACK Cholesky solve)
                         try:
-                            amp = np.linalg.solve(FNiF, FNid)
-                        except np.linalg.LinAlgError:
-                            amp = np.array([np.nan, np.nan])
-                        lnl[di, t] = 0.5 * np.dot(FNid.transpose(), amp)
-                        der[di, t] = amp
+                            lnl[di, t] = L.lnLike(th[t])
+                            der[di, t] = np.asarray(L.MLamplitude, float).ravel()
+                        except like_mod.ZeroPosterior:
+                            lnl[di, t] = np.nan
                         chi2[di, t] = np.nan
+                        if di == 0 and t == 0:               # the overwrite quirk, for the record
+                            like_mod.linalg.solve = lambda a, b, sym_pos=False, **kw: _sla.solve(
+                                a, b, assume_a="pos", **kw)
+                            g2["lnl_5_overwrite_quirk"] = np.array([L.lnLike(th[t]), lnl[di, t]])
+                            like_mod.linalg.solve = solve_compat
                     else:
                         lnl[di, t] = L.lnLike(th[t])
                         if mid == 4:
