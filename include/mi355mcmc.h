@@ -82,6 +82,14 @@ int mi355_sed_nparam(int32_t model);
 int mi355_sed_load(mi355_ctx* ctx, const mi355_sed_model* model, int64_t S, int32_t nb_max,
                    const int32_t* nb, const double* nu, const double* d, const double* sig);
 
+/* How many of the loaded sources evaluate through the clamp-free base-2 kernels (all of them for
+ * far-infrared / submillimetre photometry).  A source with a band outside those kernels' domain
+ * over the prior box (h nu/k Tmax < 0.02: a radio point; h nu/k Tmin >= 300: a mid-infrared one)
+ * evaluates through the exact OCML formulas of model.py instead - by itself: the other sources of
+ * the catalogue keep the fast kernels, and mi355_mh_run runs the two groups side by side.  Both
+ * paths hold the same 1e-12 against the reference.  -1: no catalogue loaded. */
+int64_t mi355_sed_fast_sources(mi355_ctx* ctx);
+
 /* like.lnLike(theta) (Likelihood.py:99-105 -> submmSED/likelihood.py:141-155, :99-110,
  * :35-74) for sources [s0, s0+ns) x C parameter vectors each.
  * theta: host [ns, C, P]; lnL: host [ns, C]; derived (nullable): host [ns, C, 2], the

@@ -118,6 +118,38 @@ struct LaunchStart {
   }
 };
 
+// Every source of the catalogue is in the domain of the clamp-free kernels (the incremental and the
+// extended samplers have no exact-path instantiation: mixed catalogues run k_mh_run / the step-wise
+// engine, source by source).
+static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c->nslow == 0; }
+
+// Lists of the chain blocks (bs chains each) whose sources are all fast / not all fast.
+static int build_block_lists(mi355_ctx* c, int bs) {
+  if (c->blk_bs == bs && c->blk_C == c->C) return 0;
+  const int64_t nblk = ceil_div(c->N, bs);
+  std::vector<int32_t> fast, slow;
+  for (int64_t b = 0; b < nblk; ++b) {
+    const int64_t s_lo = b * bs / c->C, s_hi = (std::min<int64_t>((b + 1) * bs, c->N) - 1) / c->C;
+    bool any = false;
+    for (int64_t s = s_lo; s <= s_hi && !any; ++s) any = c->src_slow[s] != 0;
+    (any ? slow : fast).push_back(static_cast<int32_t>(b));
+  }
+  if (c->blk_fast.alloc(std::max<size_t>(1, fast.size())) || c->blk_slow.alloc(std::max<size_t>(1, slow.size())))
+    return -2;
+  if (!fast.empty())
+    MI355_HIP(hipMemcpyAsync(c->blk_fast.p, fast.data(), fast.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice, c->stream));
+  if (!slow.empty())
+    MI355_HIP(hipMemcpyAsync(c->blk_slow.p, slow.data(), slow.size() * sizeof(int32_t),
+                             hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));               // the host vectors go out of scope
+  c->nblk_fast = static_cast<int64_t>(fast.size());
+  c->nblk_slow = static_cast<int64_t>(slow.size());
+  c->blk_bs = bs;
+  c->blk_C = c->C;
+  return 0;
+}
+
 // Whether the fused SED sampler of this context runs as k_mh_run_inc: asked for, a two-component
 // normalised model on the clamp-free path, bands within the register cache, one parameter per
 // block with block b = parameter b.
@@ -125,7 +157,7 @@ static bool incremental_applies(const mi355_ctx* c) {
   if (!c->incremental || !c->mh_ready || gmh_active(c)) return false;
   const int m = c->model.model;
   if (m != MI355_SED_M2N && m != MI355_SED_M2N_LOGA) return false;
-  if (c->kc.fast_ok == 0.0 || c->nb_most > kIncBands || c->nblock != c->mhP || c->npn != 1) return false;
+  if (!sed_all_fast(c) || c->nb_most > kIncBands || c->nblock != c->mhP || c->npn != 1) return false;
   for (int b = 0; b < c->nblock; ++b)
     if (c->blockmask[b] != (1u << b)) return false;
   return true;
@@ -138,6 +170,7 @@ struct LaunchRun {
     const int bs = pick_block(c->C, c->nbm, c->S, &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
+    if (c->kc.fast_ok != 0.0 && c->nslow > 0 && build_block_lists(c, bs)) return -2;
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
     if constexpr (M == MI355_SED_M2N || M == MI355_SED_M2N_LOGA) {
       const size_t lds_inc = lds + 2 * static_cast<size_t>(kIncBands) * bs * sizeof(double);
@@ -153,13 +186,30 @@ struct LaunchRun {
       // extended sampler: correlated / rotated proposals, co-moments (sed_mh_fused_ok checked it fits)
       constexpr int ntri = ModelTraits<M>::P * (ModelTraits<M>::P + 1) / 2;
       const size_t lds_ext = lds + static_cast<size_t>(ntri) * bs * sizeof(double);
-      MI355_REQUIRE(c->kc.fast_ok != 0.0 && lds_ext <= kLdsLimit,
+      MI355_REQUIRE(sed_all_fast(c) && lds_ext <= kLdsLimit,
                     "the extended fused sampler does not serve this catalogue (step-wise engine only)");
       hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
-    } else if (c->kc.fast_ok != 0.0)
+    } else if (sed_all_fast(c))
       hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
-    else
+    else if (c->kc.fast_ok == 0.0)
       hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
+    else {
+      // mixed catalogue: the blocks with a source outside the fast domain on stream2 (each lane
+      // follows its own source there), all the others through the fast instantiation beside them
+      MhArgs af = a, as = a;
+      af.blocklist = c->blk_fast.p;
+      as.blocklist = c->blk_slow.p;
+      MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
+      MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      hipLaunchKernelGGL((k_mh_run<M, false>), dim3(static_cast<unsigned>(c->nblk_slow)), dim3(bs), lds,
+                         c->stream2, as);
+      MI355_HIP(hipGetLastError());
+      MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
+      if (c->nblk_fast > 0)
+        hipLaunchKernelGGL((k_mh_run<M, true>), dim3(static_cast<unsigned>(c->nblk_fast)), dim3(bs), lds,
+                           c->stream, af);
+      MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
     MI355_HIP(hipGetLastError());
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
     if (!c->capturing) c->ev_valid = true;
@@ -242,8 +292,11 @@ int mi355_init(int device, uint64_t seed, mi355_ctx** out) {
   c->device = device;
   c->seed = seed;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     set_error("stream/event creation failed: %s", hipGetErrorString(e));
     mi355_free(c);
@@ -267,6 +320,12 @@ void mi355_free(mi355_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamDestroy(c->stream2);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   cl_destroy(c->cl);
@@ -340,10 +399,12 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
     *lo = static_cast<double>(l - static_cast<long double>(*hi));
   };
   c->kc = SedConsts{m->h_over_k, m->nu_b, m->prefac, m->Tmin, m->Tmax, m->bmin, m->bmax,
-                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0, 0.0, 0.0};
+                    m->nu_rescale, m->h_over_k * m->nu_b, 0.0, 0.0, 0.0, 0.0, 0.0};
   c->kc.hk_nub2 = static_cast<double>(static_cast<long double>(c->kc.hk_nub) *
                                       1.442695040888963407359924681001892137L);
   dd_log(m->nu_b, &c->kc.ln_nub_hi, &c->kc.ln_nub_lo);
+  c->kc.thick_c = static_cast<double>(log2l(static_cast<long double>(m->nu_rescale) /
+                                            static_cast<long double>(m->nu_b)));
   const bool base_is_nu = (m->model == MI355_SED_M1 || m->model == MI355_SED_M2);
   // host-side derived band fields (each rounded once, as the reference computes them)
   const size_t stride = static_cast<size_t>(kBandFields) * nb_max;
@@ -380,23 +441,38 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
               m->Tmax > 0.0 && c->kc.hk_nub2 / m->Tmax >= 0.5 &&   // 2^(y_b) - 1 by subtraction
 
               std::fmax(std::fabs(m->bmin), std::fabs(m->bmax)) * std::fabs(c->kc.ln_nub_hi) < 300.0;
+    // The band conditions are per source: a source with a band outside them (a radio point, a
+    // mid-infrared one) takes the exact path by itself and leaves the rest of the catalogue on the
+    // fast one.
+    c->src_slow.assign(static_cast<size_t>(S), 0);
+    c->nslow = 0;
     for (int64_t s = 0; s < S && ok; ++s)
       for (int j = 0; j < nb[s]; ++j) {
         const double* o = h.data() + s * stride;
         if (!(o[j * kBandFields + kF_HNU] / m->Tmin < 300.0) ||
             !(emax * std::fabs(o[j * kBandFields + kF_LHI]) < 300.0) ||
             !(m->Tmax > 0.0 && o[j * kBandFields + kF_HNU] / m->Tmax >= 0.02)) {   // 1 - 2^-y keeps >= 47 bits
-          ok = false;
+          c->src_slow[s] = 1;
+          ++c->nslow;
           break;
         }
       }
+    if (c->nslow == S) ok = false;                         // nothing left for the fast kernels
     c->kc.fast_ok = ok ? 1.0 : 0.0;
+    if (!ok) {
+      c->src_slow.assign(static_cast<size_t>(S), 1);
+      c->nslow = S;
+    }
   }
+  c->blk_bs = c->blk_C = 0;                                // block lists of the previous catalogue
+  std::vector<int32_t> nbdev(static_cast<size_t>(S));
+  for (int64_t s = 0; s < S; ++s)
+    nbdev[s] = nb[s] | ((c->kc.fast_ok != 0.0 && c->src_slow[s]) ? kNbSlow : 0);
   if (c->bands.alloc(h.size())) return -2;
   if (c->nb.alloc(static_cast<size_t>(S))) return -2;
   MI355_HIP(hipMemcpyAsync(c->bands.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice,
                            c->stream));
-  MI355_HIP(hipMemcpyAsync(c->nb.p, nb, static_cast<size_t>(S) * sizeof(int32_t),
+  MI355_HIP(hipMemcpyAsync(c->nb.p, nbdev.data(), static_cast<size_t>(S) * sizeof(int32_t),
                            hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipStreamSynchronize(c->stream));
   c->sed_loaded = true;
@@ -583,7 +659,7 @@ namespace mi355 {
 // (its extended instantiation): clamp-free fast path, parameters within the block-mask tables,
 // LDS for the band tables plus the per-lane sqrt matrix.
 bool sed_mh_fused_ok(const mi355_ctx* c) {
-  if (!c || !c->sed_loaded || c->kc.fast_ok == 0.0 || c->P > kMaxParam) return false;
+  if (!c || !c->sed_loaded || !sed_all_fast(c) || c->P > kMaxParam) return false;
   size_t lds = 0;
   const int bs = pick_block(c->C, c->nbm, c->S, &lds);
   return bs > 0 && lds + static_cast<size_t>(c->P * (c->P + 1) / 2) * bs * sizeof(double) <= kLdsLimit;
@@ -649,6 +725,11 @@ int sed_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_nor
 }  // namespace mi355
 
 extern "C" {
+
+int64_t mi355_sed_fast_sources(mi355_ctx* c) {
+  if (!c || !c->sed_loaded) return -1;
+  return c->S - c->nslow;
+}
 
 int mi355_mh_set_incremental(mi355_ctx* c, int32_t on) {
   MI355_REQUIRE(c, "null context");

@@ -104,6 +104,7 @@ struct SedConsts {
   double ln_nub_hi, ln_nub_lo;   // log2(nu_b) as a double-double
   double fast_ok;  // 1: every band keeps the fast kernels' arguments in range over the prior box
   double hk_nub2;  // hk_nub * log2(e): the normalisation argument of the fast path in base 2
+  double thick_c;  // log2(nu_rescale / nu_b): optically thick model, tau = 2^(beta (log2(nu/nu_b) - log2 nu0 - thick_c))
 };
 
 }  // namespace mi355
@@ -125,7 +126,18 @@ struct mi355_ctx {
   int nbm = 0;
   int nb_most = 0;                // largest nb[s] of the catalogue (<= nbm, the row width)
   mi355::DevBuf<double> bands;   // [S][nbm][kBandFields]
-  mi355::DevBuf<int32_t> nb;     // [S]
+  mi355::DevBuf<int32_t> nb;     // [S]: band count, + kNbSlow for a source outside the fast domain
+  // Per-source fast-path domain (mi355_sed_load): src_slow[s] = 1 when a band of source s leaves the
+  // domain of the clamp-free kernels; such sources take the exact OCML path, the others keep the fast
+  // one.  k_mh_run over a mixed catalogue: two launches over disjoint lists of chain blocks (built
+  // when the block size is known), the slow one on stream2 beside the fast one.
+  std::vector<uint8_t> src_slow;
+  int64_t nslow = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  mi355::DevBuf<int32_t> blk_fast, blk_slow;
+  int64_t nblk_fast = 0, nblk_slow = 0;
+  int blk_bs = 0, blk_C = 0;      // the (block size, chains per source) the lists were built for
 
   // --- chain state (N = S*C chains, parameter-major so lanes coalesce) --------------
   bool mh_ready = false;

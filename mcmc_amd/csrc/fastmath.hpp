@@ -275,6 +275,16 @@ __device__ __forceinline__ double log_fast(double u) {
   return fma(fe, kLn2Hi, fma(fe, kLn2Lo, lm));
 }
 
+// log2(u), u > 0 and normal: the same reduction, ln(m) scaled to base 2 and added to the exponent
+__device__ __forceinline__ double log2_fast(double u) {
+  int e = __builtin_amdgcn_frexp_exp(u);
+  double m = __builtin_amdgcn_frexp_mant(u);               // [0.5, 1)
+  const bool lo = m < 0x1.6a09e667f3bcdp-1;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  return fma(log_fast(m), kLog2e, static_cast<double>(e));  // |ln m| <= ln(2)/2: no cancellation
+}
+
 // sin(2 pi u), cos(2 pi u) for u in [0, 1): quarter-turn reduction (exact), then the fdlibm
 // kernel polynomials on |y| <= pi/4 (error < 2^-57) and a quadrant rotation by selects.
 __device__ __forceinline__ void sincos2pi_fast(double u, double* sn, double* cs) {

@@ -21,6 +21,9 @@ struct Bands {
   // weight 0 and benign values (nu = nu_b, d = 0): they add exactly 0 to a chi-square.
   int nbu;
   const double* e2t;   // stage_exp2_table() of the block: the 2^y kernel of the fast path
+  // this source may take the clamp-free fast path (SedConsts::fast_ok and its own bands in range:
+  // nb_fast() of the source's entry in the nb table)
+  bool fast;
   __device__ __forceinline__ double f(int j, int field) const { return base[j * kBandFields + field]; }
   __device__ __forceinline__ double nu(int j) const { return f(j, kF_NU); }
   __device__ __forceinline__ double hnu(int j) const { return f(j, kF_HNU); }      // h/k * nu
@@ -34,6 +37,18 @@ struct Bands {
   // h nu / k in units of ln 2: the Planck argument of the fast path comes out in base 2
   __device__ __forceinline__ double hnu2(int j) const { return f(j, kF_HNU2); }
 };
+
+// The nb table on the device: the band count of the source, plus kNbSlow when one of its bands
+// leaves the domain of the clamp-free kernels (mi355_sed_load decides, source by source).
+constexpr int32_t kNbSlow = 1 << 30;
+__device__ __forceinline__ int nb_count(int32_t raw) { return raw & (kNbSlow - 1); }
+__device__ __forceinline__ bool nb_fast(int32_t raw, const SedConsts& k) {
+  return k.fast_ok != 0.0 && (raw & kNbSlow) == 0;
+}
+__device__ __forceinline__ Bands make_bands(const double* base, int nbm, int32_t raw,
+                                            const double* e2t, const SedConsts& k) {
+  return Bands{base, nbm, nb_count(raw), nb_count(raw), e2t, nb_fast(raw, k)};
+}
 
 // max of v over the 64 lanes of the wave, as a scalar.  Every lane of the wave must be active.
 __device__ __forceinline__ int wave_max_uniform(int v) {
@@ -123,8 +138,7 @@ __device__ __forceinline__ bool all_finite(const double* th) {
 // the exact path below, transcendental kernels from fastmath.hpp; differences vs the reference
 // stay at the 1e-15 level (tests/test_sed_gpu.py).  The transcendental kernels run without their
 // argument clamps: mi355_sed_load only enables this path (SedConsts::fast_ok) when every band of
-// the catalogue keeps h nu/kT and (3+beta) ln(base) below 300 over the whole prior box.  THICK keeps the exact path (its power-law
-// base depends on the parameter nu0).
+// the catalogue keeps h nu/kT and (3+beta) ln(base) below 300 over the whole prior box.
 template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands& B,
                                                   const SedConsts& k, double* derived) {
@@ -200,6 +214,35 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double amp = FNid / FNiF;
     if (derived) derived[0] = amp;
     return 0.5 * FNid * amp;
+  } else if constexpr (MODEL == MI355_SED_THICK) {
+    // A (1 - e^-tau)/(1 - e^-tau_b) (nu/nu_b)^3 expm1(x_b)/expm1(x), tau = (nu/nu0/nu_rescale)^beta
+    // (model.py:649-657).  The optical depth in base 2: log2 tau = beta (log2(nu/nu_b) - c0) with
+    // c0 = log2(nu0 nu_rescale/nu_b) - one logarithm per evaluation, log2(nu/nu_b) is the band
+    // table's - then 1 - e^-tau through expm1 (no cancellation at small tau; 1 to the last bit
+    // beyond tau = 50); the Planck factor as in the one-component branch above with exponent 3.
+    // nu0 outside [1e-60, 1e60] (the prior only asks nu0 >= 0) would overflow the 2^z kernels:
+    // those points take the exact path.
+    const double A = th[0], b = th[1], T = th[2], nu0 = th[3];
+    if (!(nu0 > 1.0e-60 && nu0 < 1.0e60)) return sed_lnlike<MODEL>(th, B, k, derived);
+    const double c0 = log2_fast(nu0) + k.thick_c;
+    const double rT = rcp_nr2(T);
+    const double y0[2] = {k.hk_nub2 * rT, -b * c0};
+    double e0[2];
+    exp2_tab_n<2>(y0, B.e2t, e0);
+    const double taub = e0[1];
+    const double den = (taub > 50.0) ? 1.0 : -expm1_fast<false>(-taub);
+    const double cf = div_fast(A * (e0[0] - 1.0), den);    // A expm1(x_b) / (1 - e^-tau_b)
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nbu; ++j) {
+      const double y = B.hnu2(j) * rT, lh = B.lhi(j);
+      const double z[3] = {fma(3.0, lh, -y), -y, b * ((lh - c0) + B.llo(j))};
+      double pw[3];
+      exp2_tab_n<3>(z, B.e2t, pw);
+      const double t1 = (pw[2] > 50.0) ? 1.0 : -expm1_fast<false>(-pw[2]);
+      const double r = B.d(j) - div_fast((t1 * pw[0]) * cf, 1.0 - pw[1]);
+      chi2 = fma(r * B.w(j), r, chi2);
+    }
+    return -0.5 * chi2;
   } else {
     return sed_lnlike<MODEL>(th, B, k, derived);
   }
@@ -402,7 +445,7 @@ template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_auto(const double* th, double prior, const Bands& B,
                                                   const SedConsts& k, double* derived) {
   constexpr int P = ModelTraits<MODEL>::P;
-  if (k.fast_ok != 0.0 && prior > 0.0 && all_finite<P>(th)) return sed_lnlike_fast<MODEL>(th, B, k, derived);
+  if (B.fast && prior > 0.0 && all_finite<P>(th)) return sed_lnlike_fast<MODEL>(th, B, k, derived);
   return sed_lnlike<MODEL>(th, B, k, derived);
 }
 }  // namespace mi355

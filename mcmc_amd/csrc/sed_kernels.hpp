@@ -55,6 +55,8 @@ struct MhArgs {
   int mode;               // 0 uncorrelated, 1 Cholesky-correlated, 2 rotated (GmhMode)
   const double* L;        // [P][P][N] sqrtMatrix per chain (modes 1, 2)
   double* comom;          // [P][P][N], lower triangle used; null: covariance not tracked
+  // k_mh_run: the blocks (of blockDim chains) this launch runs, or null for all of them
+  const int32_t* blocklist;
 };
 
 constexpr int kStartMaxTries = 100000;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_sed_lnlike(
   double th[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) th[i] = theta[i * n_eval + e];
-  Bands B{smem + (s - s_first) * stride, nbm, nb[s], nb[s], e2t};
+  const Bands B = make_bands(smem + (s - s_first) * stride, nbm, nb[s], e2t, k);
   double der[2];
   const double v = sed_lnlike_auto<MODEL>(th, sed_prior<MODEL>(th, k), B, k, derived ? der : nullptr);
   lnl[e] = v;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{smem + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s], e2t};
+  const Bands B = make_bands(smem + (s - s_first) * stride, a.nbm, a.nb[s], e2t, a.k);
   const uint64_t sbase = static_cast<uint64_t>(a.stage) << 40;
 
   double c[P], sg[P];
@@ -259,7 +261,10 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
   const int stride = kBandFields * a.nbm;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  // a mixed catalogue runs as two launches over disjoint block lists (LaunchRun): the blocks whose
+  // sources all take the fast path, and the rest
+  const int64_t bidx = a.blocklist ? a.blocklist[blockIdx.x] : blockIdx.x;
+  const int64_t n0 = bidx * blockDim.x;
   const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
@@ -270,13 +275,17 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int64_t s = live ? n / a.C : s_first;
   // band count of the lane's source and its maximum over the wave (the lanes of a wave share the
   // source whenever C is a multiple of 64): the band loop of the fast path is scalar control flow
-  const int nb_lane = live ? a.nb[s] : 0;
+  const int32_t nb_raw = live ? a.nb[s] : 0;
+  const int nb_lane = nb_count(nb_raw);
   const int nb_wave = wave_max_uniform(nb_lane);
   if (!live) return;
 #if MI355_ABL == 3
-  Bands B{smem + (s - s_first) * stride, a.nbm, 0, 0, e2t};
+  Bands B{smem + (s - s_first) * stride, a.nbm, 0, 0, e2t, FAST};
 #else
-  Bands B{smem + (s - s_first) * stride, a.nbm, nb_lane, FAST ? nb_wave : nb_lane, e2t};
+  // FAST: every source of the block is in the fast domain (the launcher saw to it); otherwise the
+  // lane follows its own source, as sed_lnlike_auto does in every other kernel
+  Bands B{smem + (s - s_first) * stride, a.nbm, nb_lane, FAST ? nb_wave : nb_lane, e2t,
+          FAST || nb_fast(nb_raw, a.k)};
 #endif
 
   double th[P], sg[P], mu[P], m2[P];
@@ -392,8 +401,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     // and NaN passes every comparison) comes out of the fast kernels as NaN or -inf and is
     // rejected below like any bad likelihood, so the fast instantiation needs no finiteness test.
     if (prior > 0.0 && (FAST || all_finite<P>(nw))) {
-      double v = FAST ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
-                      : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
+      double v = (FAST || B.fast) ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
+                                  : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         if (prior != 1.0) v += log(prior);                 // :250
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
   const int64_t s = n / a.C;
-  Bands B{tables + (s - s_first) * stride, a.nbm, a.nb[s], a.nb[s], e2t};
+  const Bands B = make_bands(tables + (s - s_first) * stride, a.nbm, a.nb[s], e2t, a.k);
 
   double th[P], mu[P], m2[P];
   uint32_t accb[P];

@@ -106,6 +106,12 @@ class Engine:
         check(self.lib.mi355_sed_lnlike(self._h, int(s0), ns, Cc, _dp(theta), _dp(out), _dp(der)))
         return (out, der) if derived else out
 
+    @property
+    def sed_fast_sources(self):
+        """number of loaded sources inside the domain of the clamp-free kernels
+        (mi355_sed_fast_sources); the others evaluate through the exact path, source by source"""
+        return int(self.lib.mi355_sed_fast_sources(self._h))
+
     def sed_lnlike_dev(self, theta_ptr, lnl_ptr, ns, Cc, s0=0, derived_ptr=None):
         check(self.lib.mi355_sed_lnlike_dev_async(self._h, int(s0), int(ns), int(Cc),
                                                   C.c_void_p(theta_ptr), C.c_void_p(lnl_ptr),

@@ -421,6 +421,88 @@ def test_catalogue_outside_the_fast_path_domain(eng, mid):
     np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
 
 
+@pytest.mark.parametrize("mid,C", [(R.M2N, 16), (R.M1N, 100), (R.THICK, 64)])
+def test_mixed_catalogue_splits_source_by_source(mid, C):
+    """One radio point must not move a whole catalogue to the exact path: the sources with a band
+    outside the fast kernels' domain evaluate through the exact formulas by themselves, every other
+    source evaluates exactly as it does in a catalogue without them (bit for bit: same kernels, same
+    draws), likelihood batches and chains alike - chains in the two side-by-side launches of
+    mi355_mh_run, whether a fast source shares its block of chains with a slow one or not."""
+    from mcmc_amd import Engine
+    S, nsteps = 70, 40
+    P = R.MODEL_NPARAM[mid]
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=23)
+    slow = np.array([3, 41, 69])
+    nu2 = nu.copy()
+    nu2[slow[:2], 0] = 1.4                                # radio point
+    nu2[slow[2], 1] = 3.0e4                               # mid-infrared point
+    nb = np.full(S, 8, np.int32)
+    rng = np.random.default_rng(4)
+    th = truth[:, None, :P] * rng.uniform(0.8, 1.25, (S, C, P))
+    start = truth[:, None, :P].repeat(C, axis=1)
+    out = {}
+    for tag, cat in (("mixed", nu2), ("clean", nu)):
+        with Engine(seed=77) as e:
+            e.sed_load(mid, nb, cat, d, sig)
+            assert e.sed_fast_sources == (S - slow.size if tag == "mixed" else S)
+            lnl = e.sed_lnlike(th)
+            e.mh_init(C, start, np.full(P, 0.03), param_blocks=np.arange(P), randomize_start=False)
+            z, u = e.rng_dump(e.step_total, nsteps, S * C, 1)
+            e.mh_run(nsteps, thin=1)
+            tr, lp, acc = e.mh_trace()
+            e.mh_run(25)                                  # no trace
+            out[tag] = (lnl, tr, lp, acc, e.mh_moments(), z, u)
+    fast = np.setdiff1d(np.arange(S), slow)
+    for a, b in zip(out["mixed"][:4], out["clean"][:4]):
+        ax = 0 if a.ndim == 2 else 1
+        assert np.array_equal(np.take(a, fast, axis=ax), np.take(b, fast, axis=ax), equal_nan=True)
+    for k, v in out["mixed"][4].items():
+        assert np.array_equal(v[fast], out["clean"][4][k][fast], equal_nan=True), k
+    # the slow sources against the oracle: likelihood batch, and one chain of each draw for draw
+    lnl, tr, lp, _, _, z, u = out["mixed"]
+    ref = np.array([[R.sed_lnlike(mid, th[s, c], R.GaussData(nu2[s], d[s], sig[s])) for c in range(C)]
+                    for s in slow])
+    assert_lnl_close(lnl[slow], ref, RTOL_LNL, "slow sources model %d" % mid)
+    for s in slow:
+        c = int(s) % C
+        n = s * C + c
+        zz = np.zeros((nsteps, P))
+        for t in range(nsteps):
+            zz[t, t % P] = z[t, n, 0]
+        ch = R.Chain(R.sed_problem(mid, R.GaussData(nu2[s], d[s], sig[s])), np.full(P, 0.03), truth[s, :P],
+                     R.InjectedDraws(zz, u[:, n]), do_block=True, randomize_start=False)
+        ch.run(nsteps)
+        np.testing.assert_allclose(tr[:, s, c], np.asarray(ch.samples)[1:], rtol=1e-12)
+        np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
+
+
+def test_mixed_catalogue_runs_at_the_all_fast_rate():
+    """2e4 sources x 64 chains, one of them with a radio point: the chain blocks of that source run
+    through the exact path on a second stream beside the fast launch - within 10 % of the rate of
+    the same catalogue without the radio point (measured: see DESIGN.md)."""
+    from mcmc_amd import Engine
+    S, C, P = 20000, 64, 6
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=31)
+    nb = np.full(S, 8, np.int32)
+    nu2 = nu.copy()
+    nu2[S // 2, 0] = 1.4
+    ms = {}
+    for tag, cat in (("clean", nu), ("mixed", nu2)):
+        with Engine(seed=1) as e:
+            e.sed_load(R.M2N, nb, cat, d, sig)
+            e.mh_init(C, truth[:, None, :P].repeat(C, axis=1), np.full(P, 0.03),
+                      param_blocks=np.arange(P), randomize_start=False)
+            e.mh_run(200)
+            t = []
+            for _ in range(5):
+                e.mh_run(200)
+                t.append(e.last_kernel_ms)
+            ms[tag] = float(np.median(t))
+    print("200 steps of %d x %d chains: all fast %.2f ms, one slow source %.2f ms (%.3f)"
+          % (S, C, ms["clean"], ms["mixed"], ms["mixed"] / ms["clean"]))
+    assert ms["mixed"] <= 1.10 * ms["clean"]
+
+
 def test_sed_abi_errors_leave_the_context_usable():
     """Misuse of the SED / MH entry points returns an error with a message (never a fault), and
     the context keeps working afterwards."""
