@@ -14,6 +14,7 @@ struct ClData {
   bool has_x = false, has_corr = false, beam_uncertain = false, has_pol = false;
   double calib = 0.0;
   DevBuf<double> obs, xf, beam_err, bfac, ninv, nsym, var, window, K, bp0;
+  DevBuf<int32_t> krange;          // [nbp/16][2] non-zero k-step range of K per column tile (cl_bp_tile)
   DevBuf<uint8_t> hasx, inc_pol;
   DevBuf<int32_t> win_min, win_max;
 };
@@ -60,7 +61,7 @@ static ClBinning binning_of(const ClProblem* p) {
 
 static int build_K(mi355_ctx* c, ClData* d) {
   ClProblem* p = c->cl;
-  const size_t nk = static_cast<size_t>(p->npar) * d->nbp;
+  const size_t nk = static_cast<size_t>(p->npar) * cl_gstride(d->nbp);
   if (d->K.alloc(nk) || d->bp0.alloc(static_cast<size_t>(d->nbp))) return -2;
   MI355_HIP(hipMemsetAsync(d->K.p, 0, nk * sizeof(double), c->stream));
   MI355_HIP(hipMemsetAsync(d->bp0.p, 0, d->nbp * sizeof(double), c->stream));
@@ -68,6 +69,27 @@ static int build_K(mi355_ctx* c, ClData* d) {
                      d->nb, d->nbp, d->wl, d->window.p, d->win_min.p, d->win_max.p,
                      d->has_pol ? 1 : 0, d->inc_pol.p, d->K.p, d->bp0.p);
   MI355_HIP(hipGetLastError());
+  // non-zero range of every column tile (16 bands), in k-steps of four bins
+  std::vector<double> hK(nk);
+  MI355_HIP(hipMemcpyAsync(hK.data(), d->K.p, nk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  const int nct = d->nbp >> 4, gs = cl_gstride(d->nbp);
+  std::vector<int32_t> kr(static_cast<size_t>(2) * nct, 0);
+  for (int ct = 0; ct < nct; ++ct) {
+    int lo = p->npar, hi = -1;
+    for (int b = 0; b < p->npar; ++b)
+      for (int i = ct * 16; i < ct * 16 + 16; ++i)
+        if (hK[static_cast<size_t>(b) * gs + i] != 0.0) {    // NaN counts as non-zero
+          lo = std::min(lo, b);
+          hi = std::max(hi, b);
+        }
+    if (hi >= 0) {
+      kr[2 * ct] = lo >> 2;
+      kr[2 * ct + 1] = (hi >> 2) + 1;
+    }
+  }
+  if (upload(c, d->krange, kr.data(), kr.size())) return -2;
+  MI355_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -155,7 +177,7 @@ static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, 
   a.bfac = d->bfac.p;
   a.ninv = d->ninv.p;
   a.nsym = d->nsym.p;
-  a.nstride = d->nbp;
+  a.nstride = cl_gstride(d->nbp);
   a.var = d->var.p;
   a.has_x = d->has_x ? 1 : 0;
   a.beam_uncertain = d->beam_uncertain ? 1 : 0;
@@ -282,7 +304,7 @@ static void plan_fused(ClProblem* p) {
     m.f.bfac = d->bfac.p;
     m.f.ninv = d->ninv.p;
     m.f.nsym = d->nsym.p;
-    m.f.nstride = d->nbp;
+    m.f.nstride = cl_gstride(d->nbp);
     m.f.var = d->var.p;
     m.f.has_x = d->has_x ? 1 : 0;
     m.f.beam_uncertain = d->beam_uncertain ? 1 : 0;
@@ -291,6 +313,8 @@ static void plan_fused(ClProblem* p) {
     m.f.ncal = f.ncal;
     m.f.nbeam = f.nbeam;
     m.K = d->K.p;
+    m.kstride = cl_gstride(d->nbp);
+    m.krange = d->krange.p;
     m.bp0 = d->bp0.p;
     m.has_corr = d->has_corr ? 1 : 0;
     m.rows_per_chain = f.rows_per_chain;
@@ -459,24 +483,25 @@ int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
     if (upload(c, d->window, s.window, static_cast<size_t>(nb) * 3 * s.win_len)) return -2;
     std::vector<double> pad, sym;   // staging; must outlive the copies below
     if (d->has_corr) {
-      pad.assign(static_cast<size_t>(nbp) * nbp, 0.0);
+      const size_t gs = static_cast<size_t>(cl_gstride(nbp));   // row stride in HBM
+      pad.assign(static_cast<size_t>(nbp) * gs, 0.0);
       for (int r = 0; r < nb; ++r)
-        std::memcpy(&pad[static_cast<size_t>(r) * nbp], s.N_inv + static_cast<size_t>(r) * nb,
+        std::memcpy(&pad[static_cast<size_t>(r) * gs], s.N_inv + static_cast<size_t>(r) * nb,
                     nb * sizeof(double));
-      // 16 zero rows beyond the matrix: k_cl_form fetches its fragments four k-steps ahead
-      if (upload(c, d->ninv, pad.data(), pad.size(), pad.size() + static_cast<size_t>(16) * nbp)) return -2;
+      // zero rows beyond the matrix: the form fetches its fragments up to eight k-steps ahead
+      if (upload(c, d->ninv, pad.data(), pad.size(), pad.size() + kClFormSlackRows * gs)) return -2;
       // block-upper symmetrised copy for the diagonal forms (k_cl_form SYM): one rounding per
       // off-diagonal entry, none at all when N^-1 is exactly symmetric
       sym.assign(pad.size(), 0.0);
       for (int r = 0; r < nbp; ++r)
         for (int q = 0; q < nbp; ++q) {
           const int I = r >> 4, J = q >> 4;
-          if (I == J) sym[static_cast<size_t>(r) * nbp + q] = pad[static_cast<size_t>(r) * nbp + q];
+          if (I == J) sym[static_cast<size_t>(r) * gs + q] = pad[static_cast<size_t>(r) * gs + q];
           else if (I < J)
-            sym[static_cast<size_t>(r) * nbp + q] =
-                pad[static_cast<size_t>(r) * nbp + q] + pad[static_cast<size_t>(q) * nbp + r];
+            sym[static_cast<size_t>(r) * gs + q] =
+                pad[static_cast<size_t>(r) * gs + q] + pad[static_cast<size_t>(q) * gs + r];
         }
-      if (upload(c, d->nsym, sym.data(), sym.size(), sym.size() + static_cast<size_t>(16) * nbp)) return -2;
+      if (upload(c, d->nsym, sym.data(), sym.size(), sym.size() + kClFormSlackRows * gs)) return -2;
     } else {
       pad.assign(static_cast<size_t>(nbp), 1.0);
       std::memcpy(pad.data(), s.var, nb * sizeof(double));
@@ -561,7 +586,7 @@ int mi355_cl_lnlike_dev_async(mi355_ctx* c, int64_t n, const double* q_dev, doub
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
     hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
                        static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
-                       d->nbp, q_dev, d->K.p, d->bp0.p, p->bp.p);
+                       d->nbp, q_dev, d->K.p, d->krange.p, d->bp0.p, p->bp.p);
     MI355_HIP(hipGetLastError());
     int rc = dataset_from_bp(c, d.get(), p->bp.p, n, lnL_dev, first ? 0 : 1, nullptr);
     if (rc) return rc;
@@ -655,7 +680,7 @@ int mi355_cl_bandpowers(mi355_ctx* c, int32_t idata, int32_t what, int64_t n, co
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
     hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
                        static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
-                       d->nbp, p->q_pm.p, d->K.p, d->bp0.p, p->bp.p);
+                       d->nbp, p->q_pm.p, d->K.p, d->krange.p, d->bp0.p, p->bp.p);
     MI355_HIP(hipGetLastError());
   } else {
     int rc = bp_from_cl(c, d, n, in, rows, L);

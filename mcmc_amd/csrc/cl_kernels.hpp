@@ -41,10 +41,10 @@ struct ClFormArgs {
   const uint8_t* hasx;     // [nbp]
   const double* beam_err;  // [nbp] (zeros when !beam_uncertain)
   const double* bfac;      // [11][nbp] beam factors 1 + beam_err*ib*3/5, ib = -5..5 (k_cl_beam_factors)
-  const double* ninv;      // [nbp][nbp] zero padded (full covariance) ...
+  const double* ninv;      // [nbp + 16][nstride] zero padded (full covariance) ...
   const double* nsym;      // [nbp][nbp] block-upper symmetrised copy: tile (I,J), I<J, holds
                            // N_IJ + N_JI^T, diagonal tiles N_II, tiles I>J unused (k_cl_form SYM)
-  int nstride;             // row stride of ninv / nsym in doubles (nbp, or padded for an LDS copy)
+  int nstride;             // row stride of ninv / nsym in doubles (cl_gstride in HBM, cl_mh_nstride in an LDS copy)
   const double* var;       // ... or [nbp] variances (uncorrelated errors)
   int has_x;               // dataset has_xfactors
   int beam_uncertain;
@@ -54,6 +54,12 @@ struct ClFormArgs {
   int64_t rows;            // total rows = n * rows_per_chain (3 per chain in TRIPLE mode)
   double* out;             // MARGE: chisq[rows]; TRIPLE: G[n][9]
 };
+
+// Row stride (doubles) of the matrices in HBM (K, N^-1 and its symmetrised copy): nbp + 16.  With a
+// stride of nbp = 256 doubles (2 KB = 16 cache lines) every row of a column tile starts on the same
+// L2 channel, and the blocks of the fused Metropolis-Hastings kernel - all reading the same tile at
+// the same time - queue on it (measured: band powers 13.9k -> see profiles/r2_clmh_summary.txt).
+__host__ __device__ inline int cl_gstride(int nbp) { return nbp + 16; }
 
 // (chain, sub-index) of global row `grow`: sub = marginalisation point (MARGE), row type
 // (TRIPLE) or 0 (RAW, where "chain" is the row itself); chain = -1 for rows past the end.
@@ -67,31 +73,34 @@ __device__ __forceinline__ void cl_row_decode(const ClFormArgs& a, int64_t grow,
 }
 
 // Value of element `k` (band) of the row (c, sub): the vector the quadratic form is taken of.
+// TAS / IOAS: address space of the data set's tables and matrices / of a.bp and a.out (ldas in
+// common.hpp; 0 where the compiler sees the kernel argument itself).
+template <int TAS = 0, int IOAS = 0>
 __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int sub, int k) {
   if (c < 0 || k >= a.nb) return 0.0;
-  const double bp = a.bp[static_cast<int64_t>(k) * a.n + c];
+  const double bp = ldas<IOAS>(a.bp + static_cast<int64_t>(k) * a.n + c);
   if (a.mode == CL_ROWS_RAW) return bp;                    // getquadform(vec)
   if (a.mode == CL_ROWS_TRIPLE) {
-    if (sub == 0) return a.obs[k] - bp;                    // getdelta without x-factors, :396
+    if (sub == 0) return ldas<TAS>(a.obs + k) - bp;        // getdelta without x-factors, :396
     if (sub == 1) return bp;                               // :289
-    return a.beam_uncertain ? a.beam_err[k] * bp : 0.0;    // :293
+    return a.beam_uncertain ? ldas<TAS>(a.beam_err + k) * bp : 0.0;    // :293
   }
   double v = bp;
   if (a.nbeam > 1) {                                       // :333-334
     const int ib = sub / a.ncal - kClHalfSteps;
-    v *= 1.0 + a.beam_err[k] * ib * 3 / kClHalfSteps;
+    v *= 1.0 + ldas<TAS>(a.beam_err + k) * ib * 3 / kClHalfSteps;
   }
   if (a.ncal > 1) {                                        // :337-338
     const int ic = sub % a.ncal - kClHalfSteps;
     const double calib = 1.0 + a.calib * ic * 3 / kClHalfSteps;
     v = calib * v;
   }
-  if (a.has_x && a.hasx[k]) {                              // :383-392
-    double zth = v + a.xf[k];
+  if (a.has_x && ldas<TAS>(a.hasx + k)) {                  // :383-392
+    double zth = v + ldas<TAS>(a.xf + k);
     if (zth <= 0.0) zth = 0.0;                             // forces -inf rather than NaN, :389
-    return a.obs[k] - log(zth);
+    return ldas<TAS>(a.obs + k) - log(zth);
   }
-  return a.obs[k] - v;
+  return ldas<TAS>(a.obs + k) - v;
 }
 
 // Full-covariance forms on the FP64 matrix cores.  NW waves per block (4 or 8); the block owns
@@ -118,8 +127,21 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 // may then point into LDS (a.n = chains of the block), `row0` is the tile's first row and `smem`
 // the tile's LDS region (form_lds_bytes in cl_api.hip).  All 64*NW threads of the block must call
 // it; it ends without a barrier (the caller synchronises before it touches `smem` again).
-template <int RT, int CG, int MODE, int NW, bool SYM>
+// PF: how many k-steps ahead the matrix fragments are fetched (4, or 8 where few waves share a
+// SIMD and the matrix comes from L2: the fused kernel's streamed data sets); the matrix carries
+// kClFormSlackRows zero rows for the fetches past its end.
+constexpr int kClFormSlackRows = 32;
+#ifdef MI355_CLMH_PROF
+// phase timing of cl_form_tile (block 0, PROF builds only): staging, MFMA loop + epilogue, reduction
+__device__ long long g_clf[4];
+__device__ long long g_clf_t;
+#define CLF_TICK(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { const long long n_ = clock64(); if ((k) >= 0) g_clf[(k) & 3] += n_ - g_clf_t; g_clf_t = n_; } } while (0)
+#else
+#define CLF_TICK(k) do {} while (0)
+#endif
+template <int RT, int CG, int MODE, int NW, bool SYM, int PF = 4, int TAS = 0, int IOAS = 0>
 __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t row0, double* smem) {
+  static_assert(PF == 4 || PF == 8, "fetch distance");
   static_assert(!SYM || (CG == 1 && MODE != CL_ROWS_TRIPLE), "SYM needs CG == 1 and a diagonal form");
   constexpr int TR = 16 * RT;
   constexpr int NTHR = 64 * NW;
@@ -131,6 +153,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
 
+  CLF_TICK(-1);
   if (tid < TR) {
     int c = -1, sub = 0;
     if (tid < rows_used) cl_row_decode(a, row0 + tid, c, sub);
@@ -147,16 +170,21 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     // no marginalisation over one of the two: the centre point of its grid, whose factor is
     // exactly 1 (the beam-factor table always exists; multiplying by 1.0 changes nothing)
     double calib = 1.0;
-    const double* bf = a.bfac + static_cast<size_t>(kClHalfSteps) * a.nbp;
+    const auto bfac_t = as_ptr<TAS>(a.bfac);
+    const auto xf_t = as_ptr<TAS>(a.xf);
+    const auto obs_t = as_ptr<TAS>(a.obs);
+    const auto hasx_t = as_ptr<TAS>(a.hasx);
+    const auto bp_t = as_ptr<IOAS>(a.bp);
+    auto bf = bfac_t + static_cast<size_t>(kClHalfSteps) * a.nbp;
     if (marge && c >= 0) {
       if (a.ncal > 1) calib = 1.0 + a.calib * (sub % a.ncal - kClHalfSteps) * 3 / kClHalfSteps;   // :337
-      if (a.nbeam > 1) bf = a.bfac + static_cast<size_t>(sub / a.ncal) * a.nbp;                   // :334
+      if (a.nbeam > 1) bf = bfac_t + static_cast<size_t>(sub / a.ncal) * a.nbp;                   // :334
     }
     const bool has_x = a.has_x != 0;
     constexpr int KS = NTHR / TR;                          // bands between a thread's iterations
     if constexpr (!marge) {
 #pragma unroll 4
-      for (int k = tid / TR; k < a.nbp; k += KS) vt[k * TR + r] = cl_row_value(a, c, sub, k);
+      for (int k = tid / TR; k < a.nbp; k += KS) vt[k * TR + r] = cl_row_value<TAS, IOAS>(a, c, sub, k);
     } else {
       // Four bands per trip: all operand loads first (the tables are padded to nbp, indices
       // clamped), then the arithmetic, every lane computing the logarithm whether it needs it
@@ -168,11 +196,11 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int k = min(k0 + u * KS, a.nbp - 1);
-          bpv[u] = a.bp[static_cast<int64_t>(k) * a.n + cc];
+          bpv[u] = bp_t[static_cast<int64_t>(k) * a.n + cc];
           bfv[u] = bf[k];
-          xfv[u] = a.xf[k];
-          obv[u] = a.obs[k];
-          hx[u] = a.hasx[k];
+          xfv[u] = xf_t[k];
+          obv[u] = obs_t[k];
+          hx[u] = hasx_t[k];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -195,6 +223,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     }
   }
   __syncthreads();
+  CLF_TICK(0);
 
   const int nct = a.nbp >> 4;
   const int lk = lane >> 4, lc = lane & 15;
@@ -207,7 +236,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
       for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
   const size_t kstride = static_cast<size_t>(4) * a.nstride;
-  const double* nmat = SYM ? a.nsym : a.ninv;
+  const auto nmat = as_ptr<TAS>(SYM ? a.nsym : a.ninv);
   for (int pass = 0;; ++pass) {
     int ct0;
     if (SYM) {
@@ -226,7 +255,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
       for (int j = 0; j < CG; ++j) acc[rt][j] = double4_t{0.0, 0.0, 0.0, 0.0};
     // a column tile past the end is computed as a duplicate of the first one and dropped in the
     // epilogue: no branch inside the MFMA loop
-    const double* nb_ptr[CG];
+    as_ptr_t<TAS, const double> nb_ptr[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
       const int ct = (ct0 + NW * j < nct) ? ct0 + NW * j : ct0;
@@ -238,13 +267,13 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     // barriers keep the compiler from sinking the fetches next to their use.  The fetches run
     // up to four k-steps past the end: the matrix is allocated with 16 zero rows of slack and
     // the row tile is followed by the reduction scratch in LDS, and nothing read there is used.
-    double av[2][RT], bv[4][CG];
-    const double* bp[CG];
+    double av[2][RT], bv[PF][CG];
+    as_ptr_t<TAS, const double> bp[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bv[u][j] = nb_ptr[j][u * kstride];
-      bp[j] = nb_ptr[j] + 4 * kstride;
+      for (int u = 0; u < PF; ++u) bv[u][j] = nb_ptr[j][u * kstride];
+      bp[j] = nb_ptr[j] + PF * kstride;
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) av[0][rt] = va_ptr[rt * 16];
@@ -254,9 +283,10 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
 #else
     const int ksteps = SYM ? (ct0 + 1) * 4 : a.nbp >> 2;   // a multiple of 4
 #endif
-    for (int ks = 0; ks < ksteps; ks += 4) {
+    for (int ks = 0; ks < ksteps; ks += PF) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PF; ++u) {
+        if (PF > 4 && u >= 4 && ks + u >= ksteps) break;   // uniform (ksteps is a multiple of 4)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) av[(u + 1) & 1][rt] = ap[rt * 16];
         ap += 4 * TR;
@@ -298,6 +328,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
         }
     }
   }
+  CLF_TICK(1);
   // reduce over the 16 lanes that share (lane>>4), i.e. over columns
   constexpr int nt = NT;
 #pragma unroll
@@ -314,6 +345,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
         if (lc == 0) red[(w * TR + rt * 16 + lk + 4 * i) * 3 + t] = v;
       }
   __syncthreads();
+  const auto out_t = as_ptr<IOAS>(a.out);
   for (int idx = tid; idx < rows_used * nt; idx += NTHR) {
     const int r = idx / nt, t = idx - r * nt;
     const int c = rowc[r];
@@ -321,9 +353,10 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     double s = red[r * 3 + t];
 #pragma unroll
     for (int ww = 1; ww < NW; ++ww) s += red[(ww * TR + r) * 3 + t];
-    if constexpr (MODE == CL_ROWS_TRIPLE) a.out[static_cast<int64_t>(c) * 9 + rows[r] * 3 + t] = s;   // G[c][type][t]
-    else a.out[row0 + r] = s;
+    if constexpr (MODE == CL_ROWS_TRIPLE) out_t[static_cast<int64_t>(c) * 9 + rows[r] * 3 + t] = s;   // G[c][type][t]
+    else out_t[row0 + r] = s;
   }
+  CLF_TICK(2);
 }
 
 template <int RT, int CG, int MODE, int NW, bool SYM>
@@ -336,31 +369,32 @@ __global__ __launch_bounds__(64 * NW, 2) void k_cl_form(ClFormArgs a) {
 // Uncorrelated errors (has_corr_errors False): sum(vec**2/var), vec/var (:412, :420).
 // One thread per row (MARGE) or per chain (TRIPLE), bands in ascending order like the
 // reference's builtin sum().
+template <int TAS = 0, int IOAS = 0>
 __device__ __forceinline__ void cl_form_diag_item(const ClFormArgs& a, const int64_t i) {
   if (a.mode == CL_ROWS_TRIPLE) {
     if (i >= a.n) return;
     double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < a.nb; ++k) {
       double v[3];
-      for (int t = 0; t < 3; ++t) v[t] = cl_row_value(a, static_cast<int>(i), t, k);
-      const double var = a.var[k];
+      for (int t = 0; t < 3; ++t) v[t] = cl_row_value<TAS, IOAS>(a, static_cast<int>(i), t, k);
+      const double var = ldas<TAS>(a.var + k);
       g[0] += v[0] * v[0] / var;                         // getquadform, :420
       for (int t = 1; t < 3; ++t) {
         const double lin = v[t] / var;                   // getlinform, :412
         for (int u = 0; u < 3; ++u) g[t * 3 + u] += v[u] * lin;
       }
     }
-    for (int t = 0; t < 9; ++t) a.out[i * 9 + t] = g[t];
+    for (int t = 0; t < 9; ++t) stas<IOAS>(a.out + i * 9 + t, g[t]);
   } else {
     if (i >= a.rows) return;
     double s = 0.0;
     int c, sub;
     cl_row_decode(a, i, c, sub);
     for (int k = 0; k < a.nb; ++k) {
-      const double v = cl_row_value(a, c, sub, k);
-      s += v * v / a.var[k];
+      const double v = cl_row_value<TAS, IOAS>(a, c, sub, k);
+      s += v * v / ldas<TAS>(a.var + k);
     }
-    a.out[i] = s;
+    stas<IOAS>(a.out + i, s);
   }
 }
 
@@ -391,18 +425,27 @@ struct ClCombineArgs {
 };
 
 // -2 ln( sum_i w_i exp(-(c_i - min)/2) / norm ) + min over an 11-point grid, :340-354
+// CAS: address space of the chi-squares c (0: generic, e.g. a local array)
+template <int CAS = 0>
 __device__ __forceinline__ double cl_marge11(const double* c, int stride, const double* w,
                                              double norm) {
-  double mn = c[0];
+  double cv[kClGrid], wv[kClGrid];
+  for (int i = 0; i < kClGrid; ++i) {
+    cv[i] = ldas<CAS>(c + i * stride);
+    wv[i] = ldas<1>(w + i);                                // margeweights: always in HBM
+  }
+  double mn = cv[0];
   for (int i = 1; i < kClGrid; ++i) {
-    const double v = c[i * stride];
+    const double v = cv[i];
     if (v < mn) mn = v;                                  // Python min(): first smallest, NaN-blind
   }
   double s = 0.0;
-  for (int i = 0; i < kClGrid; ++i) s += w[i] * exp(-(c[i * stride] - mn) / 2);
+  for (int i = 0; i < kClGrid; ++i) s += wv[i] * exp(-(cv[i] - mn) / 2);
   return -2 * log(s / norm) + mn;
 }
 
+// IOAS: address space of a.form and a.lnl (a.neglnl is only given by the batched path: generic)
+template <int IOAS = 0>
 __device__ __forceinline__ void cl_combine_chain(const ClCombineArgs& a, const int64_t c) {
   if (c >= a.n) return;
   double chisq;
@@ -410,25 +453,25 @@ __device__ __forceinline__ void cl_combine_chain(const ClCombineArgs& a, const i
     const int npc = a.ncal * a.nbeam;
     const double* f = a.form + c * npc;
     if (npc == 1) {
-      chisq = f[0];
+      chisq = ldas<IOAS>(f);
     } else {
       double cc[kClGrid];
       for (int ib = 0; ib < a.nbeam; ++ib) {
         if (a.ncal > 1) {
-          cc[ib] = cl_marge11(f + ib * a.ncal, 1, a.weights, a.margenorm);
+          cc[ib] = cl_marge11<IOAS>(f + ib * a.ncal, 1, a.weights, a.margenorm);
         } else {
           // calib_uncertainty == 0: the 11 calibration points are the same number and the
           // weighted mean of exp(0) is exactly 1 (same summation order as margenorm)
-          cc[ib] = f[ib];
+          cc[ib] = ldas<IOAS>(f + ib);
         }
       }
-      chisq = (a.nbeam > 1) ? cl_marge11(cc, 1, a.weights, a.margenorm) : cc[0];
+      chisq = (a.nbeam > 1) ? cl_marge11<0>(cc, 1, a.weights, a.margenorm) : cc[0];
     }
   } else {                                               // analytic, :286-313
     const double* g = a.form + c * 9;
-    chisq = g[0];
-    const double chi2op = g[3], chi2pp = g[4];
-    const double chi2od = g[6], chi2pd = g[7], chi2dd = g[8];
+    chisq = ldas<IOAS>(g);
+    const double chi2op = ldas<IOAS>(g + 3), chi2pp = ldas<IOAS>(g + 4);
+    const double chi2od = ldas<IOAS>(g + 6), chi2pd = ldas<IOAS>(g + 7), chi2dd = ldas<IOAS>(g + 8);
     double denom = 1.0, wpp = 0.0;
     bool touched = false;
     if (a.calib > 1.0e-4) {
@@ -448,7 +491,7 @@ __device__ __forceinline__ void cl_combine_chain(const ClCombineArgs& a, const i
   }
   const double neg = chisq / 2;                          // :315
   if (a.neglnl) a.neglnl[c] = neg;
-  if (a.lnl) a.lnl[c] = a.accumulate ? a.lnl[c] + (-neg) : (0.0 + (-neg));
+  if (a.lnl) stas<IOAS>(a.lnl + c, a.accumulate ? ldas<IOAS>(a.lnl + c) + (-neg) : (0.0 + (-neg)));
 }
 
 __global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
@@ -464,37 +507,46 @@ __global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
 // them; out[band * ostride + chain] for chains < nvalid (LDS tile of the fused sampler, or the
 // global band-major array of the batched path).  The same function serves k_cl_bandpower and
 // k_cl_mh_run, so both engines see the same band powers bit for bit.  All 64*NW threads call it.
-template <int NW>
+// KAS: address space of K and bp0 (HBM, or the LDS copy of a resident data set); OAS: of out.
+template <int NW, int KAS = 0, int OAS = 0>
 __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double* __restrict__ K,
+                                           int kstride, const int32_t* __restrict__ krange,
                                            const double* __restrict__ bp0, int nb, int nbp,
                                            double* out, int64_t ostride, int nvalid) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lk = lane >> 4, lc = lane & 15;
-  const int nct = nbp >> 4, ksteps = (P + 3) >> 2;
+  const int nct = nbp >> 4;
   constexpr int KB = 8;                                    // k-steps per fetch batch
+  const auto K_t = as_ptr<KAS>(K);
+  const auto bp0_t = as_ptr<KAS>(bp0);
+  const auto q_t = as_ptr<3>(q);
+  const auto out_t = as_ptr<OAS>(out);
   for (int ct = w; ct < nct; ct += NW) {
     const int band = ct * 16 + lc;
-    const double c0 = (band < nb) ? bp0[band] : 0.0;
+    const double c0 = (band < nb) ? bp0_t[band] : 0.0;
     double4_t acc = double4_t{c0, c0, c0, c0};
-    const double* kp = K + static_cast<size_t>(lk) * nbp + band;
-    for (int k0 = 0; k0 < ksteps; k0 += KB) {
+    const auto kp = K_t + static_cast<size_t>(lk) * kstride + band;
+    // K is banded (a band's window meets a few bins): only the k-steps (groups of four bins) that
+    // hold a non-zero of this column tile are multiplied - the others add exact zeros
+    const int ks0 = krange[2 * ct], ks1 = krange[2 * ct + 1];
+    for (int k0 = ks0; k0 < ks1; k0 += KB) {
       double bv[KB], av[KB];
 #pragma unroll
       for (int u = 0; u < KB; ++u) {
         const int b = 4 * (k0 + u) + lk;
-        const bool live = b < P;
-        bv[u] = live ? kp[static_cast<size_t>(4 * (k0 + u)) * nbp] : 0.0;
-        av[u] = live ? q[b * 16 + lc] : 0.0;
+        const bool live = b < P && k0 + u < ks1;
+        bv[u] = live ? kp[static_cast<size_t>(4 * (k0 + u)) * kstride] : 0.0;
+        av[u] = live ? q_t[b * 16 + lc] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < KB; ++u)
-        if (k0 + u < ksteps)                               // uniform
+        if (k0 + u < ks1)                                  // uniform
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = lk + 4 * i;
-      if (row < nvalid) out[static_cast<int64_t>(band) * ostride + row] = (band < nb) ? acc[i] : 0.0;
+      if (row < nvalid) out_t[static_cast<int64_t>(band) * ostride + row] = (band < nb) ? acc[i] : 0.0;
     }
   }
 }
@@ -503,6 +555,7 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
 __global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int nb, int nbp,
                                                       const double* __restrict__ q,
                                                       const double* __restrict__ K,
+                                                      const int32_t* __restrict__ krange,
                                                       const double* __restrict__ bp0,
                                                       double* __restrict__ bp) {
   extern __shared__ double ql[];                           // [npar][16]
@@ -513,7 +566,7 @@ __global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int n
     ql[e] = (r < nvalid) ? q[static_cast<int64_t>(b) * n + c0 + r] : 0.0;
   }
   __syncthreads();
-  cl_bp_tile<4>(ql, npar, K, bp0, nb, nbp, bp + c0, n, nvalid);
+  cl_bp_tile<4>(ql, npar, K, cl_gstride(nbp), krange, bp0, nb, nbp, bp + c0, n, nvalid);
 }
 
 struct ClBinning {
@@ -547,7 +600,7 @@ __global__ void k_cl_build_K(ClBinning m, int nb, int nbp, int wl, const double*
                        window[(static_cast<size_t>(i) * 3 + iCl) * wl + l];
       const int b = m.binof[iCl * (m.lmax + 1) + l];
       if (b < 0) z += t;
-      else K[b * nbp + i] += t;
+      else K[b * cl_gstride(nbp) + i] += t;
     }
   bp0[i] = z;
 }
@@ -640,7 +693,7 @@ __global__ __launch_bounds__(256) void k_cl_linform(int64_t n, int nb, int nbp,
     return;
   }
   double s = 0.0;
-  for (int k = 0; k < nb; ++k) s = fma(ninv[static_cast<size_t>(i) * nbp + k], vec[c * nb + k], s);
+  for (int k = 0; k < nb; ++k) s = fma(ninv[static_cast<size_t>(i) * cl_gstride(nbp) + k], vec[c * nb + k], s);
   out[e] = s;
 }
 

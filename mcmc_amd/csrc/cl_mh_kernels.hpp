@@ -43,12 +43,13 @@ constexpr int kClMhMaxData = 4;      // data sets whose descriptors travel in th
 
 struct ClMhData {            // one data set (device pointers)
   ClFormArgs f;              // its tables; bp / n / rows / out are filled in per block
-  const double* K;           // [npar][nbp]
+  const double* K;           // [npar][kstride]
   const double* bp0;         // [nbp]
+  const int32_t* krange;     // [nbp/16][2]: the k-steps of K that hold a non-zero of each column tile
   int has_corr;              // full covariance (MFMA form) or variances only
   int rows_per_chain;        // 1 / 11 / 121 marginalisation points, or 3 (analytic: TRIPLE)
   int sym;                   // the form of this data set runs on the symmetrised matrix
-  int pad;
+  int kstride;               // row stride of K in doubles (cl_gstride in HBM, nbp in an LDS copy)
 };
 
 struct ClMhArgs {
@@ -115,14 +116,14 @@ __host__ __device__ inline int cl_mh_form_kind(const ClMhData& D) {
   return D.sym ? CLMH_SYM : CLMH_MARGE;
 }
 
-template <int NW, int FORM>
+template <int NW, int FORM, int PF, int TAS>
 __device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& f, double* tile) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int kind = FORM != CLMH_ANY ? FORM : cl_mh_form_kind(D);
   if (kind == CLMH_DIAG) {
     const int64_t work = (f.mode == CL_ROWS_TRIPLE) ? f.n : f.rows;
-    for (int64_t i = tid; i < work; i += NT) cl_form_diag_item(f, i);
+    for (int64_t i = tid; i < work; i += NT) cl_form_diag_item<TAS, 3>(f, i);
     return;
   }
   const int rows_used = (kind == CLMH_TRIPLE) ? 15 : 16;
@@ -130,9 +131,9 @@ __device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& 
   for (int it = 0; it < ntiles; ++it) {
     if (it) __syncthreads();                             // the previous tile is done with `tile`
     const int64_t row0 = static_cast<int64_t>(it) * rows_used;
-    if (kind == CLMH_TRIPLE) cl_form_tile<1, 1, CL_ROWS_TRIPLE, NW, false>(f, row0, tile);
-    else if (kind == CLMH_SYM) cl_form_tile<1, 1, CL_ROWS_MARGE, NW, true>(f, row0, tile);
-    else cl_form_tile<1, 1, CL_ROWS_MARGE, NW, false>(f, row0, tile);
+    if (kind == CLMH_TRIPLE) cl_form_tile<1, 1, CL_ROWS_TRIPLE, NW, false, PF, TAS, 3>(f, row0, tile);
+    else if (kind == CLMH_SYM) cl_form_tile<1, 1, CL_ROWS_MARGE, NW, true, PF, TAS, 3>(f, row0, tile);
+    else cl_form_tile<1, 1, CL_ROWS_MARGE, NW, false, PF, TAS, 3>(f, row0, tile);
   }
 }
 
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   const ClMhArgs& a = *ap;
   static_assert(!RES || FORM != CLMH_ANY, "a resident kernel is compiled for its form");
   constexpr int NT = 64 * NW, CB = kClMhChains, G = NT / CB, MS = kClMhSlots;
+  constexpr int TAS = RES ? 3 : 1;                       // the data set's tables and matrices: LDS copy or HBM
   extern __shared__ double smem[];
   const GmhArgs& g = a.g;
   const int P = g.pb.P;                                   // <= MS * G (host check)
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     double* p = resid;
     if (D0.has_corr) {
       const double* src = D0.sym ? D0.f.nsym : D0.f.ninv;
-      for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[e];
+      const int gs = D0.f.nstride;
+      for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[(e / nbp) * gs + (e % nbp)];
       D0.f.ninv = D0.f.nsym = p;
       D0.f.nstride = ns;
       p += static_cast<size_t>(nbp + 16) * ns;             // 16 rows of slack: the form fetches ahead
@@ -214,8 +217,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
       D0.f.var = p;
       p += nbp;
     }
-    for (int e = tid; e < P * nbp; e += NT) p[e] = D0.K[e];
+    for (int e = tid; e < P * nbp; e += NT) p[e] = D0.K[(e / nbp) * D0.kstride + (e % nbp)];
     D0.K = p;
+    D0.kstride = nbp;
     p += static_cast<size_t>(P) * nbp;
     double* t_bp0 = p;
     double* t_obs = p + nbp;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
         if (i < P) {
           double v = rth[m];
           if (in_block(i)) {                               // :151, :156-159
-            const double zi = valid ? (inject ? inj[i] : zrow[rank_of[i] * CB]) : 0.0;
+            const double zi = valid ? (inject ? ldas<1>(inj + i) : zrow[rank_of[i] * CB]) : 0.0;
             v += zi * rsg[m];
           }
           rnew[m] = v;
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
       if (inject) {
         if (valid) {
           for (int j = grp; j < P; j += G)
-            if (g.mode == GMH_CORR) z[j * CB + cl] = inj[j];
-            else if (in_block(j)) z[j * CB + cl] = inj[rank_of[j]];
+            if (g.mode == GMH_CORR) z[j * CB + cl] = ldas<1>(inj + j);
+            else if (in_block(j)) z[j * CB + cl] = ldas<1>(inj + rank_of[j]);
         }
         __syncthreads();
       }
@@ -319,13 +323,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
               if (in_block(i)) {                           // :153-159
                 double s = 0.0;
 #pragma unroll 4
-                for (int j = 0; j < P; ++j) s += Li[j * N] * zval(j);
+                for (int j = 0; j < P; ++j) s += ldas<1>(Li + j * N) * zval(j);
                 v += s * rsg[m];
               }
             } else {                                       // :145-148, sum() starts from 0
               double s = 0.0;
               for (int j = 0; j < P; ++j)
-                if (in_block(j)) s += Li[j * N] * zval(j);
+                if (in_block(j)) s += ldas<1>(Li + j * N) * zval(j);
               v += s * rsg[m];
             }
           }
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   // -ln L of one data set for the proposals in thn -> lnl (accumulated over the data sets)
   auto dataset = [&](const ClMhData& D, int id) {
     // BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i] on the matrix cores (the function k_cl_bandpower runs)
-    cl_bp_tile<NW>(thn, P, D.K, D.bp0, D.f.nb, D.f.nbp, bp, CB, CB);
+    cl_bp_tile<NW, TAS, 3>(thn, P, D.K, D.kstride, D.krange, D.bp0, D.f.nb, D.f.nbp, bp, CB, CB);
     __syncthreads();
     CLMH_TICK(1);
     ClFormArgs f = D.f;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     f.n = CB;
     f.rows = static_cast<int64_t>(CB) * D.rows_per_chain;
     f.out = fout;
-    cl_mh_form<NW, FORM>(D, f, tile);
+    cl_mh_form<NW, FORM, RES ? 4 : 8, TAS>(D, f, tile);    // streamed matrices: fetched 8 k-steps ahead
     __syncthreads();
     CLMH_TICK(2);
     if (tid < CB) {
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
       cmb.lnl = lnl;
       cmb.accumulate = id > 0 ? 1 : 0;
       cmb.neglnl = nullptr;
-      cl_combine_chain(cmb, tid);
+      cl_combine_chain<3>(cmb, tid);
     }
     // (the next data set's band powers go to `bp`, which the combine does not read; its form
     // output is written after the barrier that follows them)
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
           const double lnalpha = v - prev;                 // :251-252 (prior is 1: nothing to add)
           bool reject = false;
           if (!(lnalpha >= 0.0)) {
-            const double u = g.inj_u ? g.inj_u[t * N + n]
+            const double u = g.inj_u ? ldas<1>(g.inj_u + t * N + n)
                                      : uc[ts * CB + cl];                        // = uniform(step)
             reject = !(exp_accept(lnalpha, e2t) > u);      // :264
           }
@@ -424,8 +428,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
           if (g.nblock) accb[blk * CB + cl] += 1;          // :271
         }
         if (keep) {
-          g.tr_lnPr[row * N + n] = accepted ? v : prev;
-          g.tr_acc[row * N + n] = accepted ? 1 : 0;
+          stas<1>(g.tr_lnPr + row * N + n, accepted ? v : prev);
+          stas<1>(g.tr_acc + row * N + n, static_cast<uint8_t>(accepted ? 1 : 0));
         }
       }
       dec[cl] = accepted ? 1.0 : 0.0;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
           if (g.comom != nullptr) dl[i * CB + cl] = dlt;
           rmu[m] = fma(dlt, rn, rmu[m]);
           rm2[m] = fma(dlt, x - rmu[m], rm2[m]);
-          if (keep && valid) g.tr_theta[(row * P + i) * N + n] = x;
+          if (keep && valid) stas<1>(g.tr_theta + (row * P + i) * N + n, x);
         }
       }
     }
@@ -472,12 +476,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
               gmh_tri_decode(e, i, j);
               ptr[u] = g.comom + (static_cast<int64_t>(i) * P + j) * N + n;
               inc[u] = cf * dl[i * CB + cl] * dl[j * CB + cl];
-              cur[u] = *ptr[u];
+              cur[u] = ldas<1>(ptr[u]);
             }
           }
 #pragma unroll
           for (int u = 0; u < U; ++u)
-            if (ptr[u]) *ptr[u] = cur[u] + inc[u];
+            if (ptr[u]) stas<1>(ptr[u], cur[u] + inc[u]);
         }
       }
     }
@@ -486,9 +490,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   }
 #ifdef MI355_CLMH_PROF
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-    printf("clmh block %d steps %lld: moments+propose %lld bp %lld form %lld accept %lld (ticks per step)\n",
+    printf("clmh block %d steps %lld: moments+propose %lld bp %lld form %lld accept %lld (ticks per step); "
+           "form since load: stage %lld mfma %lld reduce %lld (cumulative ticks, block 0)\n",
            blockIdx.x, (long long)a.nsteps, pt[0] / a.nsteps, pt[1] / a.nsteps, pt[2] / a.nsteps,
-           pt[3] / a.nsteps);
+           pt[3] / a.nsteps, g_clf[0], g_clf[1], g_clf[2]);
 #endif
 
   // ---- state back to HBM ----

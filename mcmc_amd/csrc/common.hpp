@@ -98,6 +98,36 @@ void gmh_destroy(GmhState*);
 
 inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Loads / stores through a pointer whose address space the caller knows (AS = 1 global, 3 LDS,
+// 0 generic).  A pointer that reaches a kernel through a struct in memory is generic to the
+// compiler: it becomes a FLAT access, which counts on both vmcnt and lgkmcnt and can only be waited
+// for with both at zero - every prefetch in flight is drained at the next LDS read.  The fused
+// kernels name the address space where they know it.
+// Pointer type in address space AS, and the cast to it.  Cast the BASE pointer once and index the
+// result: every generic -> LDS cast costs a null check (four VALU instructions).
+template <int AS, typename T> struct AsPtr { using type = T*; };
+template <typename T> struct AsPtr<1, T> { using type = __attribute__((address_space(1))) T*; };
+template <typename T> struct AsPtr<3, T> { using type = __attribute__((address_space(3))) T*; };
+template <int AS, typename T>
+using as_ptr_t = typename AsPtr<AS, T>::type;
+template <int AS, typename T>
+__device__ __forceinline__ as_ptr_t<AS, T> as_ptr(T* p) {
+  return (as_ptr_t<AS, T>)p;
+}
+
+template <int AS, typename T>
+__device__ __forceinline__ T ldas(const T* p) {
+  if constexpr (AS == 3) return *(const __attribute__((address_space(3))) T*)p;
+  else if constexpr (AS == 1) return *(const __attribute__((address_space(1))) T*)p;
+  else return *p;
+}
+template <int AS, typename T>
+__device__ __forceinline__ void stas(T* p, T v) {
+  if constexpr (AS == 3) *(__attribute__((address_space(3))) T*)p = v;
+  else if constexpr (AS == 1) *(__attribute__((address_space(1))) T*)p = v;
+  else *p = v;
+}
+
 struct SedConsts {
   double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
