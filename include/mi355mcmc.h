@@ -157,6 +157,18 @@ int mi355_mh_run(mi355_ctx* ctx, int64_t nsteps, int32_t thin, const double* inj
 int mi355_mh_set_incremental(mi355_ctx* ctx, int32_t on);
 int mi355_mh_incremental_active(mi355_ctx* ctx);
 
+/* Lane mapping of the fused SED sampler.  lane = chain (a lane walks the nb bands of its source)
+ * fills the GPU once the job has chains enough; lanes = (chain, band) - G = 8 or 32 lanes hold one
+ * chain and each evaluates one band, the chi-square terms are then added in band order - shortens a
+ * step from nb band evaluations to one and is what a small job wants (one source, a handful of
+ * chains: the reference's own use).  mode 0 (default): (chain, band) when chains x G <= 65 536 lanes
+ * (one wave per SIMD of the GPU), lane = chain beyond; 1 / 2 force either.  The chains are the same
+ * bit for bit under both mappings.  (chain, band) applies to uncorrelated proposals on a catalogue
+ * that is wholly on the fast path with at most 32 bands per source (not SEDLikelihood2);
+ * mi355_mh_lane_group: the G the next mi355_mh_run of this context would use (1, 8 or 32). */
+int mi355_mh_set_lane_map(mi355_ctx* ctx, int32_t mode);
+int mi355_mh_lane_group(mi355_ctx* ctx);
+
 /* mean(burn=1), stdev(burn=1)**2 (ddof=0, MCMC.py:290-307) over the steps run since the last
  * init/adapt, naccept (MCMC.py:179,269), per-block accept counts (:181,271) and the current
  * lnPr / position.  Host outputs, all nullable: mean,var,theta [S,C,P]; naccept,lnPr [S,C];

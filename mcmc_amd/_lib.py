@@ -68,6 +68,8 @@ SIGNATURES = {
                                    c_double_p, c_double_p]),
     "mi355_mh_sigmas": (C.c_int, [C.c_void_p, c_double_p]),
     "mi355_sed_fast_sources": (C.c_int64, [C.c_void_p]),
+    "mi355_mh_set_lane_map": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mi355_mh_lane_group": (C.c_int, [C.c_void_p]),
     "mi355_mh_set_incremental": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi355_mh_incremental_active": (C.c_int, [C.c_void_p]),
     "mi355_mh_stream_pos": (C.c_int64, [C.c_void_p, C.c_int32]),

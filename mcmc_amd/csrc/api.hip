@@ -123,6 +123,22 @@ struct LaunchStart {
 // engine, source by source).
 static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c->nslow == 0; }
 
+// Lanes per chain of the next plain k_mh_run launch (uncorrelated proposals, whole catalogue on the
+// fast path): 1 = lane per chain; 8 / 32 = lanes (chain, band), picked when the job is too small to
+// give every SIMD of the GPU a wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has
+// the crossover there, 2.4x (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
+// mi355_mh_set_lane_map overrides (tests hold the two mappings to identical chains).
+static int sed_lane_group(const mi355_ctx* c) {
+  if (c->lane_map == 1 || !sed_all_fast(c) || c->model.model == MI355_SED_M2) return 1;
+  const int g = c->nb_most <= 8 ? 8 : (c->nb_most <= 32 ? 32 : 0);
+  if (g == 0 || c->nb_most < 2) return 1;
+  size_t lds = 0;
+  const int bs = pick_block(c->C, c->nbm, c->S, &lds);
+  if (bs <= 0 || lds + 16 + static_cast<size_t>(bs) * sizeof(double2) > kLdsLimit) return 1;   // exchange slots
+  if (c->lane_map == 2) return g;
+  return c->N * g <= 65536 ? g : 1;
+}
+
 // Lists of the chain blocks (bs chains each) whose sources are all fast / not all fast.
 static int build_block_lists(mi355_ctx* c, int bs) {
   if (c->blk_bs == bs && c->blk_C == c->C) return 0;
@@ -189,9 +205,21 @@ struct LaunchRun {
       MI355_REQUIRE(sed_all_fast(c) && lds_ext <= kLdsLimit,
                     "the extended fused sampler does not serve this catalogue (step-wise engine only)");
       hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
-    } else if (sed_all_fast(c))
-      hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
-    else if (c->kc.fast_ok == 0.0)
+    } else if (sed_all_fast(c)) {
+      const int G = sed_lane_group(c);
+      const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, bs / (G > 0 ? G : 1)));
+      if constexpr (M != MI355_SED_M2) {
+        const size_t lds_g = lds + 16 + static_cast<size_t>(bs) * sizeof(double2);   // + the exchange slots
+        if (G == 8)
+          hipLaunchKernelGGL((k_mh_run<M, true, false, 8>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        else if (G == 32)
+          hipLaunchKernelGGL((k_mh_run<M, true, false, 32>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        else
+          hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
+      } else {
+        hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
+      }
+    } else if (c->kc.fast_ok == 0.0)
       hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
     else {
       // mixed catalogue: the blocks with a source outside the fast domain on stream2 (each lane
@@ -725,6 +753,19 @@ int sed_mh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_nor
 }  // namespace mi355
 
 extern "C" {
+
+int mi355_mh_set_lane_map(mi355_ctx* c, int32_t mode) {
+  MI355_REQUIRE(c, "null context");
+  MI355_REQUIRE(mode >= 0 && mode <= 2, "lane map %d: 0 automatic, 1 lane = chain, 2 lanes = (chain, band)", mode);
+  c->lane_map = mode;
+  return 0;
+}
+
+int mi355_mh_lane_group(mi355_ctx* c) {
+  if (!c || !c->mh_ready || gmh_active(c)) return -1;
+  if (incremental_applies(c)) return 1;
+  return sed_lane_group(c);
+}
 
 int64_t mi355_sed_fast_sources(mi355_ctx* c) {
   if (!c || !c->sed_loaded) return -1;

@@ -180,6 +180,7 @@ struct mi355_ctx {
   int32_t rank_in_block[mi355::kMaxParam] = {0};
   int npn = 1;                    // normals drawn per step in free-running mode
   bool incremental = false;       // mi355_mh_set_incremental: k_mh_run_inc where it applies
+  int lane_map = 0;               // mi355_mh_set_lane_map: 0 automatic, 1 lane = chain, 2 lanes = (chain, band)
   bool mh_fused = true;           // mi355_mh_set_fused: step-wise problems run their fused kernel where one exists
   int64_t step_total = 0;         // Philox stream position (never reset)
   int64_t stage_step = 0;         // steps since the last init/adapt (iBlock = stage_step % nblock)

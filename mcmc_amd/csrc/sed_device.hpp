@@ -248,6 +248,132 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
   }
 }
 
+// ---- likelihood, fast path, lanes = (chain, band) ---------------------------------------------
+// The same function as sed_lnlike_fast for a chain that owns G consecutive lanes (G = 8 or 32, a
+// power of two >= the source's bands): lane jb of the group evaluates band jb, then every lane
+// gathers the band terms and adds them in band order - the very sequence of fused multiply-adds the
+// one-lane loop runs, so the value is identical bit for bit.  North_star's primary mapping (SURVEY
+// App. C): it shortens a step from nb band evaluations to one, and pays when the chains of the job
+// do not fill the machine (tools/ubench_lanemap.hip: 2.4x at nb = 27, 1.6x at nb = 8 up to ~4 000
+// chains; a third of the lane = chain rate once every SIMD has a wave of its own).  Every lane of
+// the group must call it with the same th (they hold copies of the chain); nbu is the wave-uniform
+// bound of sed_lnlike_fast (padding rows add exact zeros there and here).
+// The gather goes through LDS: the lane parks its pair in its own 16-byte slot, then reads the
+// group's slots in band order (one 128-bit broadcast read per band; four cross-lane permutes per
+// band otherwise).  The group is part of one wave, whose LDS operations execute in order: no
+// barrier, only a fence that keeps the compiler from moving the reads above the write.
+__device__ __forceinline__ void cb_publish(double2* slot, double a, double b) {
+  *slot = make_double2(a, b);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double cb_chi2_in_order(double rw, double r, int nbu, double2* slot, int jb) {
+  cb_publish(slot, rw, r);
+  const double2* grp = slot - jb;
+  double chi2 = 0.0;
+  for (int j = 0; j < nbu; ++j) {
+    const double2 v = grp[j];
+    chi2 = fma(v.x, v.y, chi2);
+  }
+  return chi2;
+}
+
+template <int MODEL, int G>
+__device__ __forceinline__ double sed_lnlike_fast_cb(const double* th, const Bands& B,
+                                                     const SedConsts& k, int jb, double2* slot) {
+  const bool mine = jb < B.nbm;                            // rows nb <= jb < nbm: padding, weight 0
+  if constexpr (MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA ||
+                MODEL == MI355_SED_THICK_LOGA) {
+    const double A = (MODEL == MI355_SED_M1N) ? th[0] : exp10_fast(th[0]);
+    const double T = th[2], e3 = 3.0 + th[1];
+    const double rT = rcp_nr2(T);
+    const double ae = A * (exp2_tab(k.hk_nub2 * rT, B.e2t) - 1.0);
+    double r = 0.0, rw = 0.0;
+    if (mine) {
+      const double y = B.hnu2(jb) * rT;
+      const double z[2] = {fma(e3, B.lhi(jb), -y), -y};
+      double pw[2];
+      exp2_tab_n<2>(z, B.e2t, pw);
+      const double n = pw[0] * ae, dn = 1.0 - pw[1];
+      r = B.d(jb) - div_fast(n, dn);
+      rw = r * B.w(jb);
+    }
+    return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
+  } else if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+    const bool lg = (MODEL == MI355_SED_M2N_LOGA);
+    const double A1 = lg ? exp10_fast(th[0]) : th[0];
+    const double A2 = lg ? exp10_fast(th[3]) : th[3];
+    const double T1 = th[2], T2 = th[5];
+    const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
+    const double rT1 = rcp_nr2(T1), rT2 = rcp_nr2(T2);
+    const double yb[2] = {k.hk_nub2 * rT1, k.hk_nub2 * rT2};
+    double eb[2];
+    exp2_tab_n<2>(yb, B.e2t, eb);
+    const double ae1 = A1 * (eb[0] - 1.0);
+    const double ae2 = A2 * (eb[1] - 1.0);
+    double r = 0.0, rw = 0.0;
+    if (mine) {
+      const double hn = B.hnu2(jb), lh = B.lhi(jb);
+      const double y1 = hn * rT1, y2 = hn * rT2;
+      const double z[4] = {fma(e1, lh, -y1), -y1, fma(e2, lh, -y2), -y2};
+      double pw[4];
+      exp2_tab_n<4>(z, B.e2t, pw);
+      const double n1 = pw[0] * ae1, d1 = 1.0 - pw[1];
+      const double n2 = pw[2] * ae2, d2 = 1.0 - pw[3];
+      r = B.d(jb) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
+      rw = r * B.w(jb);
+    }
+    return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
+  } else if constexpr (MODEL == MI355_SED_M1) {
+    const double T = th[1], e3 = 3.0 + th[0];
+    if (T > k.Tmax) return sed_lnlike<MODEL>(th, B, k, nullptr);   // as sed_lnlike_fast: every lane, in full
+    const double pre = k.prefac * pow2_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
+    const double rT = 1.0 / T;
+    double g = 0.0, gw = 0.0;
+    if (jb < B.nb) {
+      const double y = B.hnu2(jb) * rT;
+      g = div_fast(pre * exp2_fast(fma(e3, B.lhi(jb), -y)), 1.0 - exp2_fast(-y));
+      gw = g * B.w(jb);
+    }
+    cb_publish(slot, gw, g);
+    const double2* grp = slot - jb;
+    double FNiF = 0.0, FNid = 0.0;
+    for (int j = 0; j < B.nb; ++j) {                       // the group's own count, as the one-lane loop
+      const double2 v = grp[j];
+      FNiF = fma(v.x, v.y, FNiF);
+      FNid = fma(v.x, B.d(j), FNid);
+    }
+    const double amp = FNid / FNiF;
+    return 0.5 * FNid * amp;
+  } else if constexpr (MODEL == MI355_SED_THICK) {
+    const double A = th[0], b = th[1], T = th[2], nu0 = th[3];
+    if (!(nu0 > 1.0e-60 && nu0 < 1.0e60)) return sed_lnlike<MODEL>(th, B, k, nullptr);
+    const double c0 = log2_fast(nu0) + k.thick_c;
+    const double rT = rcp_nr2(T);
+    const double y0[2] = {k.hk_nub2 * rT, -b * c0};
+    double e0[2];
+    exp2_tab_n<2>(y0, B.e2t, e0);
+    const double taub = e0[1];
+    const double den = (taub > 50.0) ? 1.0 : -expm1_fast<false>(-taub);
+    const double cf = div_fast(A * (e0[0] - 1.0), den);
+    double r = 0.0, rw = 0.0;
+    if (mine) {
+      const double y = B.hnu2(jb) * rT, lh = B.lhi(jb);
+      const double z[3] = {fma(3.0, lh, -y), -y, b * ((lh - c0) + B.llo(jb))};
+      double pw[3];
+      exp2_tab_n<3>(z, B.e2t, pw);
+      const double t1 = (pw[2] > 50.0) ? 1.0 : -expm1_fast<false>(-pw[2]);
+      r = B.d(jb) - div_fast((t1 * pw[0]) * cf, 1.0 - pw[1]);
+      rw = r * B.w(jb);
+    }
+    return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
+  } else {
+    return sed_lnlike<MODEL>(th, B, k, nullptr);           // SEDLikelihood2: no fast path (host never picks G > 1)
+  }
+}
+
 // ---- pieces of the incremental sampler (k_mh_run_inc) ------------------------------------------
 // The normalised greybody of ONE component at every band of the source, without its amplitude:
 //   u[j] = (nu_j/nu_b)^(3+beta) expm1(h nu_b/kT) / expm1(h nu_j/kT)            model.py:107-109

@@ -255,8 +255,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // step: only adaptation stages track them).  Same draws, same arithmetic as k_gmh_propose /
 // k_gmh_accept: tests/test_gmh_gpu.py holds the two to identical chains.  A separate instantiation,
 // so the uncorrelated production kernel keeps its registers.
-template <int MODEL, bool FAST, bool EXT = false>
+// G: lanes per chain.  1: lane = chain (the lane loops over the bands) - the layout that fills the
+// machine once there are chains enough for it.  8 / 32: lanes = (chain, band), G lanes hold copies of
+// one chain and each evaluates one band (sed_lnlike_fast_cb; lane 0 of the group writes the chain's
+// state) - north_star's primary mapping, which the host picks for jobs too small to give every SIMD
+// a wave (sed_lane_group in api.hip).  Same draws, same arithmetic in the same order: the chains are
+// identical bit for bit under either mapping (tests/test_sed_gpu.py).
+template <int MODEL, bool FAST, bool EXT = false, int G = 1>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
+  static_assert(G == 1 || (FAST && !EXT), "(chain, band) lanes: fast path, uncorrelated proposals");
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -264,13 +271,16 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   // a mixed catalogue runs as two launches over disjoint block lists (LaunchRun): the blocks whose
   // sources all take the fast path, and the rest
   const int64_t bidx = a.blocklist ? a.blocklist[blockIdx.x] : blockIdx.x;
-  const int64_t n0 = bidx * blockDim.x;
-  const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
+  const int cpb = blockDim.x / G;                          // chains per block
+  const int64_t n0 = bidx * cpb;
+  const int64_t n_last = min(n0 + cpb, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
   const double* e2t = stage_exp2_table();
   stage_bands(smem, a.bands, s_first, nsrc, stride);
-  const int64_t n = n0 + threadIdx.x;
+  const int64_t n = n0 + threadIdx.x / G;
+  const int jb = threadIdx.x % G;                          // the lane's band (G > 1)
+  const bool writer = G == 1 || jb == 0;                   // the lane that stores the chain's state
   const bool live = n < a.N;
   const int64_t s = live ? n / a.C : s_first;
   // band count of the lane's source and its maximum over the wave (the lanes of a wave share the
@@ -302,6 +312,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   uint32_t nacc = a.naccept[n];
   // EXT: this chain's sqrt matrix, lower triangle row by row, in the lane's LDS column
   double* Ll = smem + static_cast<size_t>(nsrc) * stride + threadIdx.x;
+  // G > 1: the lane's 16-byte slot of the band-term exchange, behind the band tables
+  double2* cb_slot = reinterpret_cast<double2*>(smem + ((static_cast<size_t>(nsrc) * stride + 1) & ~static_cast<size_t>(1))) + threadIdx.x;
   if constexpr (EXT) {
     if (a.mode != 0) {
 #pragma unroll
@@ -401,8 +413,10 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     // and NaN passes every comparison) comes out of the fast kernels as NaN or -inf and is
     // rejected below like any bad likelihood, so the fast instantiation needs no finiteness test.
     if (prior > 0.0 && (FAST || all_finite<P>(nw))) {
-      double v = (FAST || B.fast) ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
-                                  : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
+      double v;
+      if constexpr (G > 1) v = sed_lnlike_fast_cb<MODEL, G>(nw, B, a.k, jb, cb_slot);
+      else v = (FAST || B.fast) ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
+                                : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243
       if (!bad) {
         if (prior != 1.0) v += log(prior);                 // :250
@@ -460,15 +474,18 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     if (a.thin > 0) {
       if (++thin_ctr == a.thin) {
         thin_ctr = 0;
+        if (writer) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) a.tr_theta[(row * P + i) * a.N + n] = th[i];
-        a.tr_lnPr[row * a.N + n] = lnPr;
-        a.tr_acc[row * a.N + n] = accepted ? 1 : 0;
+          for (int i = 0; i < P; ++i) a.tr_theta[(row * P + i) * a.N + n] = th[i];
+          a.tr_lnPr[row * a.N + n] = lnPr;
+          a.tr_acc[row * a.N + n] = accepted ? 1 : 0;
+        }
         ++row;
       }
     }
   }
 
+  if (!writer) return;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     a.theta[i * a.N + n] = th[i];

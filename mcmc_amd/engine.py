@@ -106,6 +106,16 @@ class Engine:
         check(self.lib.mi355_sed_lnlike(self._h, int(s0), ns, Cc, _dp(theta), _dp(out), _dp(der)))
         return (out, der) if derived else out
 
+    def mh_set_lane_map(self, mode):
+        """0 automatic, 1 lane = chain, 2 lanes = (chain, band) in the fused SED sampler
+        (mi355_mh_set_lane_map); same chains either way"""
+        check(self.lib.mi355_mh_set_lane_map(self._h, int(mode)))
+
+    @property
+    def mh_lane_group(self):
+        """lanes per chain the next mh_run would use (1, 8 or 32; -1: no fused SED chains)"""
+        return int(self.lib.mi355_mh_lane_group(self._h))
+
     @property
     def sed_fast_sources(self):
         """number of loaded sources inside the domain of the clamp-free kernels

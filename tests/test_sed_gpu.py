@@ -503,6 +503,93 @@ def test_mixed_catalogue_runs_at_the_all_fast_rate():
     assert ms["mixed"] <= 1.10 * ms["clean"]
 
 
+def _start_point(mid, truth):
+    P = R.MODEL_NPARAM[mid]
+    if mid == R.M1:
+        return truth[:, 1:3].copy()
+    if mid == R.M2:
+        return truth[:, [1, 2, 4, 5]].copy()
+    th = truth[:, :P].copy()
+    if mid in (R.M1N_LOGA, R.M2N_LOGA, R.THICK_LOGA):
+        th[:, 0] = np.log10(th[:, 0])
+    if mid == R.M2N_LOGA:
+        th[:, 3] = np.log10(th[:, 3])
+    if mid in (R.THICK, R.THICK_LOGA):
+        th[:, 3] = 0.7
+    return th
+
+
+@pytest.mark.parametrize("mid", [R.M1N, R.M1N_LOGA, R.M2N, R.M2N_LOGA, R.M1, R.THICK, R.THICK_LOGA])
+@pytest.mark.parametrize("nbands,G", [(8, 8), (27, 32)])
+def test_lane_mappings_give_identical_chains(mid, nbands, G):
+    """North_star's two lane mappings of the fused sampler - lane = chain, and lanes = (chain, band)
+    with the chi-square terms added in band order - produce the same chains bit for bit: traces,
+    moments, accept counts; block proposals and all-parameter proposals, free-running and injected
+    draws, ragged band counts, chain counts that do not fill a block."""
+    from mcmc_amd import Engine
+    S, C, nsteps = 5, 7, 60
+    P = R.MODEL_NPARAM[mid]
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=29, nb=nbands)
+    nb = np.full(S, nbands, np.int32)
+    nb[1] = nbands - 2
+    nb[3] = max(1, nbands // 2)
+    th0 = _start_point(mid, truth)
+    rng = np.random.default_rng(8)
+    zn = rng.standard_normal((25, S * C, P))
+    zu = rng.uniform(size=(25, S * C))
+    out = {}
+    for lane_map in (1, 2):
+        res = []
+        with Engine(seed=2024) as e:
+            e.mh_set_lane_map(lane_map)
+            e.sed_load(mid, nb, nu, d, sig)
+            for blocks in (np.arange(P), None):
+                e.mh_init(C, th0[:, None, :].repeat(C, axis=1), np.full(P, 0.02), param_blocks=blocks,
+                          randomize_start=False)
+                assert e.mh_lane_group == (G if lane_map == 2 else 1)
+                e.mh_run(nsteps, thin=1)
+                res.append(e.mh_trace())
+                e.mh_run(33)
+                e.mh_run(25, thin=5, inj_normals=zn, inj_uniforms=zu)
+                res.append(e.mh_trace())
+                res.append(e.mh_moments())
+        out[lane_map] = res
+    for a, b in zip(out[1], out[2]):
+        if isinstance(a, dict):
+            for k in a:
+                assert np.array_equal(a[k], b[k], equal_nan=True), k
+        else:
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y, equal_nan=True)
+    assert out[1][0][2].mean() > 0.05                     # the chains did move
+
+
+def test_lane_mapping_is_picked_by_job_size():
+    """Automatic choice: (chain, band) while chains x G fit one wave per SIMD, lane = chain beyond;
+    lane = chain wherever the band-parallel kernel does not apply."""
+    from mcmc_amd import Engine
+    nu, d, sig, truth = R.synth_sed_catalogue(300, seed=2)
+    nb = np.full(300, 8, np.int32)
+    with Engine(seed=1) as e:
+        e.sed_load(R.M2N, nb[:4], nu[:4], d[:4], sig[:4])
+        e.mh_init(16, truth[0], np.full(6, 0.02), param_blocks=np.arange(6))
+        assert e.mh_lane_group == 8                       # 64 chains
+        e.mh_set_incremental(True)
+        assert e.mh_lane_group == 1                       # the incremental sampler is lane = chain
+        e.mh_set_incremental(False)
+        e.sed_load(R.M2N, nb, nu, d, sig)
+        e.mh_init(64, truth[0], np.full(6, 0.02), param_blocks=np.arange(6))
+        assert e.mh_lane_group == 1                       # 19 200 chains x 8 lanes > 65 536
+        e.sed_load(R.M2, nb[:4], nu[:4], d[:4], sig[:4])
+        e.mh_init(16, truth[0, [1, 2, 4, 5]], np.full(4, 0.02), param_blocks=np.arange(4))
+        assert e.mh_lane_group == 1                       # SEDLikelihood2 has no fast path
+        nu2 = nu[:4].copy()
+        nu2[2, 0] = 1.4
+        e.sed_load(R.M2N, nb[:4], nu2, d[:4], sig[:4])
+        e.mh_init(16, truth[0], np.full(6, 0.02), param_blocks=np.arange(6))
+        assert e.mh_lane_group == 1                       # a source on the exact path
+
+
 def test_sed_abi_errors_leave_the_context_usable():
     """Misuse of the SED / MH entry points returns an error with a message (never a fault), and
     the context keeps working afterwards."""
