@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STEP = 1342.0        # 2-comp, 8 bands, 1 transcendental = 32 FP64 FLOP
 PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vector FP64)
 # HBM bytes per chain per launch of k_mh_run<M2N>, from the PMC passes in
-# profiles/r1_bench_summary.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
+# profiles/r2_bench_summary.txt (same figures as r1): (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
 # State is read and written once per launch whatever the number of inner steps.
 HBM_BYTES_PER_CHAIN_LAUNCH = 415.7
 
