@@ -8,17 +8,18 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from mcmc_amd import Engine          # noqa: E402
-from oracle import refcpu as R       # noqa: E402  (synthetic catalogue generator only)
+from mcmc_amd import synth           # noqa: E402
+from mcmc_amd.engine import MODEL_IDS   # noqa: E402
 
 for S, C, nbands in [(1, 1, 27), (1, 4, 27), (1, 64, 27), (16, 16, 27), (64, 32, 27), (1024, 64, 27),
                      (1, 4, 8), (16, 16, 8), (256, 16, 8), (1024, 8, 8), (1024, 16, 8), (1024, 64, 8)]:
-    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=31, nb=nbands)
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=31, nb=nbands)
     nb = np.full(S, nbands, np.int32)
     row = {}
     for lane_map in (1, 2, 0):
         with Engine(seed=1) as e:
             e.mh_set_lane_map(lane_map)
-            e.sed_load(R.M2N, nb, nu, d, sig)
+            e.sed_load(MODEL_IDS["M2N"], nb, nu, d, sig)
             e.mh_init(C, truth[:, None, :].repeat(C, axis=1), np.full(6, 0.03), param_blocks=np.arange(6),
                       randomize_start=False)
             G = e.mh_lane_group

@@ -9,27 +9,30 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from mcmc_amd import Engine          # noqa: E402
-from oracle import refcpu as R       # noqa: E402  (synthetic catalogue generator only)
+from mcmc_amd import synth           # noqa: E402
+from mcmc_amd.engine import MODEL_IDS   # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-nu, d, sig, truth = R.synth_sed_catalogue(S, seed=31)
+nu, d, sig, truth = synth.sed_catalogue(S, seed=31)
 nb = np.full(S, 8, np.int32)
 nu_slow = nu.copy()
 nu_slow[:, 0] = 1.4
-names = {v: k for k, v in vars(R).items() if k in ("M1N", "M1N_LOGA", "M2N", "M2N_LOGA", "M1", "M2", "THICK", "THICK_LOGA")}
+names = {v: k for k, v in MODEL_IDS.items()}
+NPARAM = {"M1N": 3, "M1N_LOGA": 3, "M2N": 6, "M2N_LOGA": 6, "M1": 2, "M2": 4, "THICK": 4, "THICK_LOGA": 4}
+M = MODEL_IDS
 for mid in range(8):
-    P = R.MODEL_NPARAM[mid]
+    P = NPARAM[names[mid]]
     th0 = truth[:, :P].copy()
-    if mid in (R.M2N_LOGA, R.M1N_LOGA, R.THICK_LOGA):
+    if mid in (M["M2N_LOGA"], M["M1N_LOGA"], M["THICK_LOGA"]):
         th0[:, 0] = np.log10(th0[:, 0])
-    if mid == R.M2N_LOGA:
+    if mid == M["M2N_LOGA"]:
         th0[:, 3] = np.log10(th0[:, 3])
-    if mid == R.M1:
+    if mid == M["M1"]:
         th0 = truth[:, 1:3].copy()
-    if mid == R.M2:
+    if mid == M["M2"]:
         th0 = truth[:, [1, 2, 4, 5]].copy()
-    if mid in (R.THICK, R.THICK_LOGA):
+    if mid in (M["THICK"], M["THICK_LOGA"]):
         th0[:, 3] = 1.0
     row = []
     for cat in (nu, nu_slow):

@@ -192,7 +192,7 @@ static Result run(int64_t S, int C, int nb, int nsteps, int reps) {
   const double h_over_k = 0.04799237, nu_b = 1000.0;
   SedConsts k{h_over_k, nu_b, 1e-9, 3.0, 100.0, 0.0, 3.0, 1000.0, h_over_k * nu_b, 0, 0, 1.0, 0, 0};
   k.hk_nub2 = static_cast<double>(static_cast<long double>(k.hk_nub) * 1.442695040888963407359924681001892137L);
-  // synthetic two-component sources (oracle/refcpu.py synth_sed_catalogue's shape, own generator)
+  // synthetic two-component sources (the shape of mcmc_amd/synth.py's catalogue, own generator)
   std::vector<double> hb(static_cast<size_t>(S) * nbm * kBandFields);
   srand48(7);
   auto grey = [&](double A, double b, double T, double nu) {
