@@ -217,6 +217,21 @@ def test_mcmc_object_free_running_and_rhat(arp220):
         ms[0].MC_append(1)                                # its device chains moved to `new`
 
 
+def test_gelman_rubin_matches_the_reference_value(g3):
+    """G3 `rhat__value` is the reference's own gelmanrubin_MCMC (convergence.py:58-87) on five of
+    its chains; the device kernel (mi355_gelman_rubin) on those chains' means and variances must
+    return it (the fixture was only compared with the CPU oracle)."""
+    from mcmc_amd import Engine
+    ref = g3["rhat__value"]
+    means, var = g3["rhat__means"], g3["rhat__vars"]          # [5 chains, 6 parameters]
+    with Engine(seed=1) as e:
+        got = e.gelman_rubin(means, var)
+    # the reference sums over chains with numpy's pairwise mean/var, the device in chain order:
+    # identical up to the last bits
+    np.testing.assert_allclose(got, ref, rtol=1e-13)
+    assert np.all(np.isfinite(ref)) and ref.shape == (6,)
+
+
 def test_zero_prior_start_raises(arp220):
     from mcmc_amd import MCMC
     from mcmc_amd.submmSED import likelihood, model
