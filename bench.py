@@ -191,9 +191,14 @@ def main():
             left -= min(inner, left)
         eng.mh_adapt()
 
+    rhat_s = []                                               # wall time of the R-hat of every step
+
     def one_step():
-        eng.mh_run(inner)
-        return D.engine_rhat(eng, Ctot=C * world)
+        eng.mh_run(inner)                                     # synchronous: the launch has finished
+        t = time.perf_counter()
+        r = D.engine_rhat(eng, Ctot=C * world)                # two kernels (+ two all-reduces on several GPUs)
+        rhat_s.append(time.perf_counter() - t)
+        return r
 
     def barrier():
         if world > 1:
@@ -204,6 +209,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     kernel_ms = []
+    del rhat_s[:]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -211,6 +217,7 @@ def main():
         kernel_ms.append(eng.last_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    rhat_ms = 1e3 * float(np.mean(rhat_s)) if rhat_s else 0.0
     if rank == 0:
         print("kernel ms per launch:", " ".join("%.2f" % v for v in kernel_ms), file=sys.stderr)
     if world > 1:
@@ -347,6 +354,7 @@ def main():
         # convergence.py:77-85) after adapt + warmup + timed steps
         "rhat_lt_1p1_frac": float((torch.nan_to_num(rhat, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
         "rhat_allreduce_bytes": 3 * 6 * 8 * S if world > 1 else 0,
+        "rhat_ms_per_step": rhat_ms,       # R-hat of every source (kernels + collectives + their syncs), inside ms_per_step
     }
     if args.dump_rhat and rank == 0:
         np.save(args.dump_rhat, rhat.cpu().numpy())

@@ -357,12 +357,12 @@ int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn) {
   return cl_mh_plan_lds(c->cl, P, nblock, npn, 1 << 30).bytes <= kClLdsBudget ? c->cl->mh_nw : 0;
 }
 
-template <int NW, int FORM, bool RES>
+template <int NW, int FORM, bool RES, bool CMR = false>
 static int launch_cl_mh(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
   static size_t opted[kMaxDevices] = {};
   size_t& have = opted[c->device % kMaxDevices];
   if (lds > 48 * 1024 && lds > have) {
-    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_mh_run<NW, FORM, RES>),
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_mh_run<NW, FORM, RES, CMR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     have = lds;
   }
@@ -372,7 +372,7 @@ static int launch_cl_mh(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
   MI355_HIP(hipMemcpyAsync(p->mh_args.p, &a, sizeof(ClMhArgs), hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipStreamSynchronize(c->stream));
   const unsigned grid = static_cast<unsigned>(ceil_div64(a.g.N, kClMhChains));
-  hipLaunchKernelGGL((k_cl_mh_run<NW, FORM, RES>), dim3(grid), dim3(64 * NW), lds, c->stream,
+  hipLaunchKernelGGL((k_cl_mh_run<NW, FORM, RES, CMR>), dim3(grid), dim3(64 * NW), lds, c->stream,
                      static_cast<const ClMhArgs*>(p->mh_args.p));
   MI355_HIP(hipGetLastError());
   return 0;
@@ -384,6 +384,17 @@ template <int NW>
 static int launch_cl_mh_form(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
   if (a.ndata != 1) return launch_cl_mh<NW, CLMH_ANY, false>(c, a, lds);
   const bool res = a.resident != 0;
+  if constexpr (NW == 4) {
+    // resident 4-wave kernels: the running co-moments in registers when the triangle fits
+    if (res && a.g.comom != nullptr && a.g.pb.P <= kClMhCmrMaxP) {
+      switch (cl_mh_form_kind(a.data[0])) {
+        case CLMH_DIAG: return launch_cl_mh<4, CLMH_DIAG, true, true>(c, a, lds);
+        case CLMH_TRIPLE: return launch_cl_mh<4, CLMH_TRIPLE, true, true>(c, a, lds);
+        case CLMH_SYM: break;
+        default: return launch_cl_mh<4, CLMH_MARGE, true, true>(c, a, lds);
+      }
+    }
+  }
   switch (cl_mh_form_kind(a.data[0])) {
     case CLMH_DIAG:
       return res ? launch_cl_mh<NW, CLMH_DIAG, true>(c, a, lds) : launch_cl_mh<NW, CLMH_DIAG, false>(c, a, lds);

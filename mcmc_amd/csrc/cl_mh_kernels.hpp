@@ -137,8 +137,15 @@ __device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& 
   }
 }
 
-template <int NW, int FORM, bool RES>
+// CMR (resident 4-wave kernels, P <= kClMhCmrMaxP): the running co-moments of the block's chains live in
+// registers for the launch - thread (chain, group g) owns rows g and P-1-g of the chain's lower
+// triangle (P+1 entries per pair of rows: the triangle dealt evenly over the 16 groups) - instead
+// of being read and written in HBM at every step (528 entries per chain at P = 32: the traffic that
+// bounded a step at 18 us for 4096 chains).  Same update, entry by entry, as k_gmh_accept.
+constexpr int kClMhCmrMaxP = 32;
+template <int NW, int FORM, bool RES, bool CMR = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run(const ClMhArgs* __restrict__ ap) {
+  static_assert(!CMR || (RES && NW == 4), "co-moments in registers: the 512-register kernels");
   // The arguments live in device memory and are read where they are used (scalar loads): passed
   // by value, the ~1 KB of pointers and counters stays in SGPRs for the whole launch and spills.
   const ClMhArgs& a = *ap;
@@ -191,6 +198,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     rmu[m] = on ? g.mean[i * N + n] : 0.0;
     rm2[m] = on ? g.m2[i * N + n] : 0.0;
     rnew[m] = rth[m];
+  }
+  // CMR: rows rowA = group (< 16) and rowB = P-1-group (< 32) of the chain's co-moment triangle
+  constexpr int CA = CMR ? kClMhCmrMaxP / 2 : 1, CBR = CMR ? kClMhCmrMaxP : 1;
+  double cmA[CA], cmB[CBR];
+  const int rowA = grp, rowB = P - 1 - grp;
+  const bool hasA = CMR && valid && rowA <= rowB;            // the middle row of an odd P is an A row
+  const bool hasB = CMR && valid && rowB > rowA;
+  if constexpr (CMR) {
+#pragma unroll
+    for (int j = 0; j < CA; ++j)
+      cmA[j] = (hasA && j <= rowA) ? ldas<1>(g.comom + (static_cast<int64_t>(rowA) * P + j) * N + n) : 0.0;
+#pragma unroll
+    for (int j = 0; j < CBR; ++j)
+      cmB[j] = (hasB && j <= rowB) ? ldas<1>(g.comom + (static_cast<int64_t>(rowB) * P + j) * N + n) : 0.0;
   }
   for (int b = grp; b < nblk; b += G)
     accb[b * CB + cl] = (valid && g.nblock) ? g.accept[static_cast<int64_t>(b) * N + n] : 0u;
@@ -458,7 +479,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
         }
       }
     }
-    if (g.comom != nullptr) {                              // uniform over the grid
+    if constexpr (CMR) {                                   // (launched with co-moments only)
+      __syncthreads();
+      // C_ij += (n-1)/n d_i d_j for the thread's two rows: (cf d_i) d_j, as k_gmh_accept
+      const double cA = cf * (hasA ? dl[rowA * CB + cl] : 0.0);
+      const double cB = cf * (hasB ? dl[rowB * CB + cl] : 0.0);
+#pragma unroll
+      for (int j = 0; j < CBR; ++j) {
+        const double dj = dl[(j < P ? j : 0) * CB + cl];
+        if (j < CA) {
+          if (hasA && j <= rowA) cmA[j < CA ? j : 0] = cmA[j < CA ? j : 0] + cA * dj;
+        }
+        if (hasB && j <= rowB) cmB[j] = cmB[j] + cB * dj;
+      }
+    } else if (g.comom != nullptr) {                       // uniform over the grid
       __syncthreads();
       if (valid) {
         // C_ij += (n-1)/n d_i d_j, lower triangle dealt round-robin to the groups (k_gmh_accept)
@@ -497,6 +531,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
 #endif
 
   // ---- state back to HBM ----
+  if constexpr (CMR) {
+#pragma unroll
+    for (int j = 0; j < CA; ++j)
+      if (hasA && j <= rowA) stas<1>(g.comom + (static_cast<int64_t>(rowA) * P + j) * N + n, cmA[j]);
+#pragma unroll
+    for (int j = 0; j < CBR; ++j)
+      if (hasB && j <= rowB) stas<1>(g.comom + (static_cast<int64_t>(rowB) * P + j) * N + n, cmB[j]);
+  }
   if (valid) {
 #pragma unroll
     for (int m = 0; m < MS; ++m) {

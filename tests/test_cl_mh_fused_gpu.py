@@ -42,6 +42,9 @@ def problem(kind):
     if kind == "wide96":                                  # 6 column tiles: 8 waves, plain matrix
         model, d, truth = RC.synth_cl_problem(nb=96, npar=33, calib=0.0, beam=0.0, lmax=2400, seed=13)
         return model, [d], truth
+    if kind == "p32":                                     # 32 bins: the largest co-moment triangle kept in registers
+        model, d, truth = RC.synth_cl_problem(nb=64, npar=32, calib=0.0, beam=0.0, lmax=2000, seed=14)
+        return model, [d], truth
     raise ValueError(kind)
 
 
@@ -108,6 +111,15 @@ def test_fused_equals_stepwise_every_likelihood_shape(kind):
 @pytest.mark.parametrize("mode", ["uncorr_block", "corr_all", "rotate_block"])
 def test_fused_equals_stepwise_every_proposal_mode(mode):
     same(run("plain", True, mode, 37, True), run("plain", False, mode, 37, True))
+
+
+@pytest.mark.parametrize("kind", ["beam11", "calib11", "p32", "diag", "analytic", "two", "wide96"])
+def test_fused_comoments_equal_stepwise(kind):
+    """Running co-moments (covar(), MCMC.py:310-340) and the newMCMC stage they feed: in registers for
+    the resident 4-wave kernels up to 32 parameters (odd and even counts, every form), in HBM
+    otherwise (two data sets, 33 parameters) - the same numbers as the step-wise engine."""
+    C = 21
+    same(run(kind, True, "uncorr_block", C, True), run(kind, False, "uncorr_block", C, True))
 
 
 def test_fused_equals_stepwise_with_injected_draws():
