@@ -150,7 +150,8 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
   double* red = smem + static_cast<size_t>(a.nbp) * TR;    // [NW][TR][3]
   int* rowc = reinterpret_cast<int*>(red + (NW * 3 > 16 ? NW * 3 : 16) * TR);   // [TR] chain of each row
   int* rows = rowc + TR;                                   // [TR] sub-index of each row
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the column-tile loops are scalar
   constexpr int rows_used = (MODE == CL_ROWS_TRIPLE) ? (TR / 3) * 3 : TR;
 
   CLF_TICK(-1);
@@ -283,25 +284,37 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
 #else
     const int ksteps = SYM ? (ct0 + 1) * 4 : a.nbp >> 2;   // a multiple of 4
 #endif
-    for (int ks = 0; ks < ksteps; ks += PF) {
+    // one k-step: row fragment of the next step, MFMA of this one, refill of the ring slot
+    auto kstep = [&](int u, bool refill) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        if (PF > 4 && u >= 4 && ks + u >= ksteps) break;   // uniform (ksteps is a multiple of 4)
+      for (int rt = 0; rt < RT; ++rt) av[(u + 1) & 1][rt] = ap[rt * 16];
+      ap += 4 * TR;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) av[(u + 1) & 1][rt] = ap[rt * 16];
-        ap += 4 * TR;
-        __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < CG; ++j)
 #pragma unroll
-        for (int j = 0; j < CG; ++j)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u & 1][rt], bv[u][j], acc[rt][j], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u & 1][rt], bv[u][j], acc[rt][j], 0, 0, 0);
+      if (refill) {
 #pragma unroll
         for (int j = 0; j < CG; ++j) {
           bv[u][j] = bp[j][0];
           bp[j] += kstride;
         }
-        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int ks = 0;
+    for (; ks + PF <= ksteps; ks += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) kstep(u, true);
+    }
+    if constexpr (PF > 4) {
+      // ksteps is a multiple of 4: a last half turn of the ring, whose slots 0..3 hold exactly these
+      // k-steps (fetched by the last full turn, or by the prologue)
+      if (ks < ksteps) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kstep(u, false);
       }
     }
     // epilogue: Y[row][col] * V[row'][col] summed over this wave's columns
@@ -528,7 +541,8 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
     const auto kp = K_t + static_cast<size_t>(lk) * kstride + band;
     // K is banded (a band's window meets a few bins): only the k-steps (groups of four bins) that
     // hold a non-zero of this column tile are multiplied - the others add exact zeros
-    const int ks0 = krange[2 * ct], ks1 = krange[2 * ct + 1];
+    const int ks0 = __builtin_amdgcn_readfirstlane(krange[2 * ct]);      // wave-uniform: scalar loop control
+    const int ks1 = __builtin_amdgcn_readfirstlane(krange[2 * ct + 1]);
     for (int k0 = ks0; k0 < ks1; k0 += KB) {
       double bv[KB], av[KB];
 #pragma unroll
