@@ -15,6 +15,7 @@ struct ClData {
   double calib = 0.0;
   DevBuf<double> obs, xf, beam_err, bfac, ninv, nsym, var, window, K, bp0;
   DevBuf<int32_t> krange;          // [nbp/16][2] non-zero k-step range of K per column tile (cl_bp_tile)
+  int kmax = 1;                    // widest of those ranges, at least 1 (rows of the compact LDS copy: 4 * kmax per tile)
   DevBuf<uint8_t> hasx, inc_pol;
   DevBuf<int32_t> win_min, win_max;
 };
@@ -87,6 +88,7 @@ static int build_K(mi355_ctx* c, ClData* d) {
       kr[2 * ct] = lo >> 2;
       kr[2 * ct + 1] = (hi >> 2) + 1;
     }
+    d->kmax = std::max(ct == 0 ? 1 : d->kmax, kr[2 * ct + 1] - kr[2 * ct]);
   }
   if (upload(c, d->krange, kr.data(), kr.size())) return -2;
   MI355_HIP(hipStreamSynchronize(c->stream));
@@ -315,6 +317,7 @@ static void plan_fused(ClProblem* p) {
     m.K = d->K.p;
     m.kstride = cl_gstride(d->nbp);
     m.krange = d->krange.p;
+    m.kmax = d->kmax;
     m.bp0 = d->bp0.p;
     m.has_corr = d->has_corr ? 1 : 0;
     m.rows_per_chain = f.rows_per_chain;
@@ -331,23 +334,36 @@ static void plan_fused(ClProblem* p) {
 // pays when the grid is at most one block per CU (6.9 against 8.9 us per step at 4096 chains,
 // nb = 64); beyond that the streamed kernel wins because two of its blocks share a CU and hide
 // one another's latencies (5.2 us per 4096 chains at 65536 chains).
+// A single data set keeps its band tables and the compact K in LDS whenever they fit (tables = 1: the
+// kernels compiled for its form); otherwise, and for several data sets, the generic kernel reads
+// everything from L2.
 struct ClMhLds {
   size_t bytes;
-  int resident, sb;
+  int resident, tables, sb;
 };
 static ClMhLds cl_mh_plan_lds(const ClProblem* p, int P, int nblock, int npn, int64_t N) {
   const int sb = cl_mh_cache_steps(64 * p->mh_nw, npn);
-  ClMhLds r{0, 0, sb};
+  ClMhLds r{0, 0, 0, sb};
   constexpr int kCUs = 256;
-  if (p->data.size() == 1 && ceil_div64(N, kClMhChains) <= kCUs) {
-    const size_t res = cl_mh_resident_doubles(P, p->mh[0].f.nbp, p->mh[0].has_corr);
-    r.bytes = cl_mh_lds_doubles(P, nblock, npn, sb, p->mh_nbp_max, p->mh_fout, p->mh_tile_doubles, res) * 8;
-    if (r.bytes <= kClLdsBudget) {
-      r.resident = 1;
+  auto bytes = [&](size_t extra) {
+    return cl_mh_lds_doubles(P, nblock, npn, sb, p->mh_nbp_max, p->mh_fout, p->mh_tile_doubles, extra) * 8;
+  };
+  if (p->data.size() == 1) {
+    const ClMhData& m = p->mh[0];
+    const size_t tab = cl_mh_table_doubles(m.f.nbp, m.kmax, m.f.nbeam);
+    if (bytes(tab) <= kClLdsBudget) {
+      r.tables = 1;
+      const size_t mat = cl_mh_matrix_doubles(m.f.nbp, m.has_corr);
+      if (ceil_div64(N, kClMhChains) <= kCUs && bytes(tab + mat) <= kClLdsBudget) {
+        r.resident = 1;
+        r.bytes = bytes(tab + mat);
+        return r;
+      }
+      r.bytes = bytes(tab);
       return r;
     }
   }
-  r.bytes = cl_mh_lds_doubles(P, nblock, npn, sb, p->mh_nbp_max, p->mh_fout, p->mh_tile_doubles, 0) * 8;
+  r.bytes = bytes(0);
   return r;
 }
 
@@ -382,7 +398,7 @@ static int launch_cl_mh(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
 // from L2; several data sets: the generic kernel.
 template <int NW>
 static int launch_cl_mh_form(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
-  if (a.ndata != 1) return launch_cl_mh<NW, CLMH_ANY, false>(c, a, lds);
+  if (a.ndata != 1 || !a.tables) return launch_cl_mh<NW, CLMH_ANY, false>(c, a, lds);
   const bool res = a.resident != 0;
   if constexpr (NW == 4) {
     // resident 4-wave kernels: the running co-moments in registers when the triangle fits
@@ -427,6 +443,7 @@ int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t 
   a.fout_per_chain = p->mh_fout;
   a.tile_doubles = p->mh_tile_doubles;
   a.resident = plan.resident;
+  a.tables = plan.tables;
   a.sb = plan.sb;
   a.weights = p->weights.p;
   a.margenorm = p->margenorm;

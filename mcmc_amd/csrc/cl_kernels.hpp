@@ -139,7 +139,7 @@ __device__ long long g_clf_t;
 #else
 #define CLF_TICK(k) do {} while (0)
 #endif
-template <int RT, int CG, int MODE, int NW, bool SYM, int PF = 4, int TAS = 0, int IOAS = 0>
+template <int RT, int CG, int MODE, int NW, bool SYM, int PF = 4, int TAS = 0, int IOAS = 0, int MAS = TAS>
 __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t row0, double* smem) {
   static_assert(PF == 4 || PF == 8, "fetch distance");
   static_assert(!SYM || (CG == 1 && MODE != CL_ROWS_TRIPLE), "SYM needs CG == 1 and a diagonal form");
@@ -237,7 +237,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
       for (int t = 0; t < NT; ++t) part[rt][i][t] = 0.0;
 
   const size_t kstride = static_cast<size_t>(4) * a.nstride;
-  const auto nmat = as_ptr<TAS>(SYM ? a.nsym : a.ninv);
+  const auto nmat = as_ptr<MAS>(SYM ? a.nsym : a.ninv);
   for (int pass = 0;; ++pass) {
     int ct0;
     if (SYM) {
@@ -256,7 +256,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
       for (int j = 0; j < CG; ++j) acc[rt][j] = double4_t{0.0, 0.0, 0.0, 0.0};
     // a column tile past the end is computed as a duplicate of the first one and dropped in the
     // epilogue: no branch inside the MFMA loop
-    as_ptr_t<TAS, const double> nb_ptr[CG];
+    as_ptr_t<MAS, const double> nb_ptr[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
       const int ct = (ct0 + NW * j < nct) ? ct0 + NW * j : ct0;
@@ -269,7 +269,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     // up to four k-steps past the end: the matrix is allocated with 16 zero rows of slack and
     // the row tile is followed by the reduction scratch in LDS, and nothing read there is used.
     double av[2][RT], bv[PF][CG];
-    as_ptr_t<TAS, const double> bp[CG];
+    as_ptr_t<MAS, const double> bp[CG];
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
 #pragma unroll
@@ -521,7 +521,10 @@ __global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
 // global band-major array of the batched path).  The same function serves k_cl_bandpower and
 // k_cl_mh_run, so both engines see the same band powers bit for bit.  All 64*NW threads call it.
 // KAS: address space of K and bp0 (HBM, or the LDS copy of a resident data set); OAS: of out.
-template <int NW, int KAS = 0, int OAS = 0>
+// KC: K is the compact copy of the fused sampler - per column tile the rows of its non-zero k-steps
+// only, [nbp/16][kstride rows][16] with kstride = 4 * (widest k-step range of any tile); row r of
+// tile ct is bin 4 * ks0(ct) + r.
+template <int NW, int KAS = 0, int OAS = 0, bool KC = false>
 __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double* __restrict__ K,
                                            int kstride, const int32_t* __restrict__ krange,
                                            const double* __restrict__ bp0, int nb, int nbp,
@@ -538,7 +541,8 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
     const int band = ct * 16 + lc;
     const double c0 = (band < nb) ? bp0_t[band] : 0.0;
     double4_t acc = double4_t{c0, c0, c0, c0};
-    const auto kp = K_t + static_cast<size_t>(lk) * kstride + band;
+    const auto kp = KC ? K_t + (static_cast<size_t>(ct) * kstride + lk) * 16 + lc
+                       : K_t + static_cast<size_t>(lk) * kstride + band;
     // K is banded (a band's window meets a few bins): only the k-steps (groups of four bins) that
     // hold a non-zero of this column tile are multiplied - the others add exact zeros
     const int ks0 = __builtin_amdgcn_readfirstlane(krange[2 * ct]);      // wave-uniform: scalar loop control
@@ -549,7 +553,7 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
       for (int u = 0; u < KB; ++u) {
         const int b = 4 * (k0 + u) + lk;
         const bool live = b < P && k0 + u < ks1;
-        bv[u] = live ? kp[static_cast<size_t>(4 * (k0 + u)) * kstride] : 0.0;
+        bv[u] = live ? (KC ? kp[(4 * (k0 + u - ks0)) * 16] : kp[static_cast<size_t>(4 * (k0 + u)) * kstride]) : 0.0;
         av[u] = live ? q_t[b * 16 + lc] : 0.0;
       }
 #pragma unroll

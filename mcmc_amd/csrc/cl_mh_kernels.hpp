@@ -18,10 +18,11 @@
 // chains (G5) through both, draw for draw.
 //
 // Instantiations: <NW, FORM, RES>.  One data set: compiled for its form (plain / symmetrised
-// MFMA form, analytic-marginalisation triple form, uncorrelated errors); RES = its N^-1, K and
-// band tables are copied into LDS at launch (grids of at most one block per CU: a step then
-// touches L2 / HBM only for traces and co-moments), else they are streamed from L2 and two blocks
-// share a CU.  Several data sets: the generic kernel (FORM = CLMH_ANY).
+// MFMA form, analytic-marginalisation triple form, uncorrelated errors), with its band tables and
+// a compact copy of K (the non-zero k-steps of every column tile) in LDS for the launch; RES = its
+// N^-1 too (grids of at most one block per CU: a step then touches L2 / HBM only for traces and
+// co-moments), else the matrix is streamed from L2 and two blocks share a CU.  Several data sets,
+// or tables that do not fit: the generic kernel (FORM = CLMH_ANY), everything from L2.
 //
 // Measured (MI355X, 4096 chains, nb = 64, 32 bins; profiles/r2_clmh_summary.txt): a step is a
 // chain of dependent LDS / MFMA / barrier latencies with one wave per SIMD - about 1250
@@ -49,7 +50,9 @@ struct ClMhData {            // one data set (device pointers)
   int has_corr;              // full covariance (MFMA form) or variances only
   int rows_per_chain;        // 1 / 11 / 121 marginalisation points, or 3 (analytic: TRIPLE)
   int sym;                   // the form of this data set runs on the symmetrised matrix
-  int kstride;               // row stride of K in doubles (cl_gstride in HBM, nbp in an LDS copy)
+  int kstride;               // row stride of K in doubles (cl_gstride in HBM); rows per tile of the compact LDS copy
+  int kmax;                  // widest non-zero k-step range of a column tile of K (compact copy: 4 * kmax rows per tile)
+  int pad;
 };
 
 struct ClMhArgs {
@@ -60,8 +63,8 @@ struct ClMhArgs {
   int nbp_max;               // largest padded band count of the data sets
   int fout_per_chain;        // doubles of form output per chain: max(rows_per_chain, 9)
   int tile_doubles;          // LDS doubles of the form tile region (form_lds_bytes / 8)
-  int resident;              // 1: the (single) data set's matrices and tables are copied into LDS
-                             // at launch and every step reads them there
+  int resident;              // 1: the (single) data set's N^-1 is copied into LDS at launch too
+  int tables;                // 1: single data set whose tables and compact K live in LDS (FORM != ANY)
   int sb;                    // steps whose Philox draws one refill of the draw cache covers
   const double* weights;     // [11] margeweights
   double margenorm;
@@ -74,12 +77,16 @@ struct ClMhArgs {
 // wave reads per MFMA operand fall on disjoint halves of the banks.
 __host__ __device__ inline int cl_mh_nstride(int nbp) { return (nbp % 32 == 0) ? nbp + 16 : nbp; }
 
-// LDS doubles of the resident copy of one data set: N^-1 (or the variances), K, BP0, obs,
-// x-factors, beam errors, the 11 beam-factor rows, has_xfactor bytes
-__host__ __device__ inline size_t cl_mh_resident_doubles(int P, int nbp, int has_corr) {
-  size_t n = has_corr ? static_cast<size_t>(nbp + 16) * cl_mh_nstride(nbp) : static_cast<size_t>(nbp);
-  n += static_cast<size_t>(P) * nbp + static_cast<size_t>(4 + kClGrid) * nbp + nbp / 8;
-  return n;
+// LDS doubles of a single data set's tables: compact K (4 * kmax rows of 16 per column tile), BP0,
+// obs, x-factors, beam errors, variances, the beam-factor rows (all 11 when the beam is marginalised
+// numerically, else the centre row), has_xfactor bytes
+__host__ __device__ inline int cl_mh_bfac_rows(int nbeam) { return nbeam > 1 ? kClGrid : 1; }
+__host__ __device__ inline size_t cl_mh_table_doubles(int nbp, int kmax, int nbeam) {
+  return static_cast<size_t>(nbp) * 4 * kmax + static_cast<size_t>(5 + cl_mh_bfac_rows(nbeam)) * nbp + nbp / 8 + 1;
+}
+// ... and of the resident copy of its N^-1 (RES kernels, full covariance)
+__host__ __device__ inline size_t cl_mh_matrix_doubles(int nbp, int has_corr) {
+  return has_corr ? static_cast<size_t>(nbp + 16) * cl_mh_nstride(nbp) : 0;
 }
 
 // doubles of dynamic LDS the kernel needs (host and device agree through this one function)
@@ -116,7 +123,7 @@ __host__ __device__ inline int cl_mh_form_kind(const ClMhData& D) {
   return D.sym ? CLMH_SYM : CLMH_MARGE;
 }
 
-template <int NW, int FORM, int PF, int TAS>
+template <int NW, int FORM, int PF, int TAS, int MAS>
 __device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& f, double* tile) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
@@ -131,9 +138,9 @@ __device__ __forceinline__ void cl_mh_form(const ClMhData& D, const ClFormArgs& 
   for (int it = 0; it < ntiles; ++it) {
     if (it) __syncthreads();                             // the previous tile is done with `tile`
     const int64_t row0 = static_cast<int64_t>(it) * rows_used;
-    if (kind == CLMH_TRIPLE) cl_form_tile<1, 1, CL_ROWS_TRIPLE, NW, false, PF, TAS, 3>(f, row0, tile);
-    else if (kind == CLMH_SYM) cl_form_tile<1, 1, CL_ROWS_MARGE, NW, true, PF, TAS, 3>(f, row0, tile);
-    else cl_form_tile<1, 1, CL_ROWS_MARGE, NW, false, PF, TAS, 3>(f, row0, tile);
+    if (kind == CLMH_TRIPLE) cl_form_tile<1, 1, CL_ROWS_TRIPLE, NW, false, PF, TAS, 3, MAS>(f, row0, tile);
+    else if (kind == CLMH_SYM) cl_form_tile<1, 1, CL_ROWS_MARGE, NW, true, PF, TAS, 3, MAS>(f, row0, tile);
+    else cl_form_tile<1, 1, CL_ROWS_MARGE, NW, false, PF, TAS, 3, MAS>(f, row0, tile);
   }
 }
 
@@ -151,7 +158,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   const ClMhArgs& a = *ap;
   static_assert(!RES || FORM != CLMH_ANY, "a resident kernel is compiled for its form");
   constexpr int NT = 64 * NW, CB = kClMhChains, G = NT / CB, MS = kClMhSlots;
-  constexpr int TAS = RES ? 3 : 1;                       // the data set's tables and matrices: LDS copy or HBM
+  constexpr bool TABS = FORM != CLMH_ANY;                // single data set: tables and compact K in LDS
+  constexpr int TAS = TABS ? 3 : 1;                      // address space of the tables / K
+  constexpr int MAS = RES ? 3 : 1;                       // ... and of N^-1
   extern __shared__ double smem[];
   const GmhArgs& g = a.g;
   const int P = g.pb.P;                                   // <= MS * G (host check)
@@ -220,47 +229,65 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     nacc[cl] = valid ? g.naccept[n] : 0u;
     pbad[cl] = 0;
   }
-  // RES: one data set whose matrices fit - N^-1 (the copy its form uses), K and the band tables
-  // move to LDS once per launch, and a step touches HBM / L2 only for the trace and the co-moments.
+  // Single data set (FORM != ANY): its band tables and the compact K move to LDS once per launch;
+  // RES: N^-1 (the copy its form uses) too, and a step touches HBM / L2 only for the trace and the
+  // co-moments.
   ClMhData D0 = a.data[0];
-  if constexpr (RES) {
-    const int nbp = D0.f.nbp, ns = cl_mh_nstride(nbp);
+  if constexpr (TABS) {
+    const int nbp = D0.f.nbp;
     double* p = resid;
-    if (D0.has_corr) {
-      const double* src = D0.sym ? D0.f.nsym : D0.f.ninv;
-      const int gs = D0.f.nstride;
-      for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[(e / nbp) * gs + (e % nbp)];
-      D0.f.ninv = D0.f.nsym = p;
-      D0.f.nstride = ns;
-      p += static_cast<size_t>(nbp + 16) * ns;             // 16 rows of slack: the form fetches ahead
-    } else {
-      for (int e = tid; e < nbp; e += NT) p[e] = D0.f.var[e];
-      D0.f.var = p;
-      p += nbp;
+    if constexpr (RES) {
+      if (D0.has_corr) {
+        const int ns = cl_mh_nstride(nbp), gs = D0.f.nstride;
+        const double* src = D0.sym ? D0.f.nsym : D0.f.ninv;
+        for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[(e / nbp) * gs + (e % nbp)];
+        D0.f.ninv = D0.f.nsym = p;
+        D0.f.nstride = ns;
+        p += static_cast<size_t>(nbp + 16) * ns;           // 16 rows of slack: the form fetches ahead
+      }
     }
-    for (int e = tid; e < P * nbp; e += NT) p[e] = D0.K[(e / nbp) * D0.kstride + (e % nbp)];
-    D0.K = p;
-    D0.kstride = nbp;
-    p += static_cast<size_t>(P) * nbp;
+    {
+      // compact K: tile ct holds bins 4 ks0(ct) .. 4 ks0(ct) + 4 kmax - 1 (zero beyond its range / P)
+      const int rows = 4 * D0.kmax, per = rows * 16;
+      for (int e = tid; e < (nbp >> 4) * per; e += NT) {
+        const int ct = e / per, r = (e - ct * per) >> 4, cc = e & 15;
+        const int ks0 = D0.krange[2 * ct], ks1 = D0.krange[2 * ct + 1];
+        const int b = 4 * ks0 + r;
+        p[e] = (r < 4 * (ks1 - ks0) && b < P) ? D0.K[static_cast<size_t>(b) * D0.kstride + ct * 16 + cc] : 0.0;
+      }
+      D0.K = p;
+      D0.kstride = rows;
+      p += static_cast<size_t>(nbp >> 4) * per;
+    }
+    const int nbf = cl_mh_bfac_rows(D0.f.nbeam);
     double* t_bp0 = p;
     double* t_obs = p + nbp;
     double* t_xf = p + 2 * nbp;
     double* t_be = p + 3 * nbp;
-    double* t_bf = p + 4 * nbp;
-    uint8_t* t_hx = reinterpret_cast<uint8_t*>(p + (4 + kClGrid) * nbp);
+    double* t_var = p + 4 * nbp;
+    double* t_bf = p + 5 * nbp;
+    uint8_t* t_hx = reinterpret_cast<uint8_t*>(p + (5 + nbf) * nbp);
     for (int e = tid; e < nbp; e += NT) {
       t_bp0[e] = D0.bp0[e];
       t_obs[e] = D0.f.obs[e];
       t_xf[e] = D0.f.xf[e];
       t_be[e] = D0.f.beam_err[e];
+      t_var[e] = D0.has_corr ? 1.0 : D0.f.var[e];
       t_hx[e] = D0.f.hasx[e];
     }
-    for (int e = tid; e < kClGrid * nbp; e += NT) t_bf[e] = D0.f.bfac[e];
+    // beam factors: all 11 rows, or the centre row alone placed where row kClHalfSteps is expected
+    if (nbf == kClGrid) {
+      for (int e = tid; e < kClGrid * nbp; e += NT) t_bf[e] = D0.f.bfac[e];
+      D0.f.bfac = t_bf;
+    } else {
+      for (int e = tid; e < nbp; e += NT) t_bf[e] = D0.f.bfac[kClHalfSteps * nbp + e];
+      D0.f.bfac = t_bf - static_cast<ptrdiff_t>(kClHalfSteps) * nbp;
+    }
     D0.bp0 = t_bp0;
     D0.f.obs = t_obs;
     D0.f.xf = t_xf;
     D0.f.beam_err = t_be;
-    D0.f.bfac = t_bf;
+    D0.f.var = t_var;
     D0.f.hasx = t_hx;
   }
   __syncthreads();
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   // -ln L of one data set for the proposals in thn -> lnl (accumulated over the data sets)
   auto dataset = [&](const ClMhData& D, int id) {
     // BP[i][c] = BP0[i] + sum_b q[b][c] K[b][i] on the matrix cores (the function k_cl_bandpower runs)
-    cl_bp_tile<NW, TAS, 3>(thn, P, D.K, D.kstride, D.krange, D.bp0, D.f.nb, D.f.nbp, bp, CB, CB);
+    cl_bp_tile<NW, TAS, 3, TABS>(thn, P, D.K, D.kstride, D.krange, D.bp0, D.f.nb, D.f.nbp, bp, CB, CB);
     __syncthreads();
     CLMH_TICK(1);
     ClFormArgs f = D.f;
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     f.n = CB;
     f.rows = static_cast<int64_t>(CB) * D.rows_per_chain;
     f.out = fout;
-    cl_mh_form<NW, FORM, RES ? 4 : 8, TAS>(D, f, tile);    // streamed matrices: fetched 8 k-steps ahead
+    cl_mh_form<NW, FORM, RES ? 4 : 8, TAS, MAS>(D, f, tile);   // streamed matrices: fetched 8 k-steps ahead
     __syncthreads();
     CLMH_TICK(2);
     if (tid < CB) {
