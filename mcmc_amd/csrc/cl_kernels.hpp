@@ -537,6 +537,40 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
   const auto bp0_t = as_ptr<KAS>(bp0);
   const auto q_t = as_ptr<3>(q);
   const auto out_t = as_ptr<OAS>(out);
+  if constexpr (KC) {
+    // compact K: kstride = 4 * kmax rows per tile, zero outside the tile's range and beyond bin P - 1,
+    // so the k-loop needs no per-lane predicate: kmax k-steps for every tile (a zero k-step adds
+    // exact zeros); krange is the fused sampler's LDS copy
+    const int kmax = kstride >> 2;
+    const auto kr_t = as_ptr<KAS>(krange);
+    for (int ct = w; ct < nct; ct += NW) {
+      const int band = ct * 16 + lc;
+      const int ks0 = __builtin_amdgcn_readfirstlane(kr_t[2 * ct]);
+      const double c0 = (band < nb) ? bp0_t[band] : 0.0;
+      double4_t acc = double4_t{c0, c0, c0, c0};
+      const auto kp = K_t + (static_cast<size_t>(ct) * kstride + lk) * 16 + lc;
+      for (int k0 = 0; k0 < kmax; k0 += KB) {
+        double bv[KB], av[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u < kmax) {                             // uniform
+            const int bq = 4 * (ks0 + k0 + u) + lk;
+            bv[u] = kp[(4 * (k0 + u)) * 16];
+            av[u] = q_t[(bq < P ? bq : P - 1) * 16 + lc];  // rows beyond P - 1 meet zeros of K
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+          if (k0 + u < kmax) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = lk + 4 * i;
+        if (row < nvalid) out_t[static_cast<int64_t>(band) * ostride + row] = (band < nb) ? acc[i] : 0.0;
+      }
+    }
+    return;
+  }
   for (int ct = w; ct < nct; ct += NW) {
     const int band = ct * 16 + lc;
     const double c0 = (band < nb) ? bp0_t[band] : 0.0;

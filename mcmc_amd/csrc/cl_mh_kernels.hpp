@@ -82,7 +82,8 @@ __host__ __device__ inline int cl_mh_nstride(int nbp) { return (nbp % 32 == 0) ?
 // numerically, else the centre row), has_xfactor bytes
 __host__ __device__ inline int cl_mh_bfac_rows(int nbeam) { return nbeam > 1 ? kClGrid : 1; }
 __host__ __device__ inline size_t cl_mh_table_doubles(int nbp, int kmax, int nbeam) {
-  return static_cast<size_t>(nbp) * 4 * kmax + static_cast<size_t>(5 + cl_mh_bfac_rows(nbeam)) * nbp + nbp / 8 + 1;
+  return static_cast<size_t>(nbp) * 4 * kmax + static_cast<size_t>(5 + cl_mh_bfac_rows(nbeam)) * nbp + nbp / 8 + 1 +
+         nbp / 16 + 1;                                     // + the K ranges (int32 pairs)
 }
 // ... and of the resident copy of its N^-1 (RES kernels, full covariance)
 __host__ __device__ inline size_t cl_mh_matrix_doubles(int nbp, int has_corr) {
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     double* t_var = p + 4 * nbp;
     double* t_bf = p + 5 * nbp;
     uint8_t* t_hx = reinterpret_cast<uint8_t*>(p + (5 + nbf) * nbp);
+    int32_t* t_kr = reinterpret_cast<int32_t*>(p + (5 + nbf) * nbp + nbp / 8 + 1);   // [nbp/16][2]
     for (int e = tid; e < nbp; e += NT) {
       t_bp0[e] = D0.bp0[e];
       t_obs[e] = D0.f.obs[e];
@@ -283,6 +285,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
       for (int e = tid; e < nbp; e += NT) t_bf[e] = D0.f.bfac[kClHalfSteps * nbp + e];
       D0.f.bfac = t_bf - static_cast<ptrdiff_t>(kClHalfSteps) * nbp;
     }
+    for (int e = tid; e < (nbp >> 4) * 2; e += NT) t_kr[e] = D0.krange[e];
+    D0.krange = t_kr;
     D0.bp0 = t_bp0;
     D0.f.obs = t_obs;
     D0.f.xf = t_xf;
