@@ -15,11 +15,18 @@ class BeamData(GaussianData):
         self.y = np.asarray(yarr, np.float64)
         if cts is not None:
             self.cts = cts
+        self.version = 0          # bumped when stats() shifts the map: device copies are reloaded
 
     def stats(self, sigcut=None, do_abs=False):                      # :35-71
-        """(<x>, <y>, var x, var y) weighted by the mean-subtracted data.  (The reference also
-        shifts self.d in place, :52 - an acknowledged accident that is not reproduced.)"""
+        """(<x>, <y>, var x, var y) weighted by the mean-subtracted data.  As in the reference, the
+        subtraction happens IN PLACE when do_abs is false (`dd = self.d; dd -= offset`, :45-52, with
+        the author's own "IS THIS ACTUALLY SHIFTING THE self.d???"): every likelihood evaluation
+        after setup_sampler sees the mean-subtracted map (and so does the caller's array, if it was
+        float64 already).  Pinned by G12 (tests/golden/setup_sampler_g12.json)."""
         from ..engine import Engine
+        if not do_abs:
+            self.d -= self.d.mean()
+            self.version += 1
         with Engine() as eng:
             eng.beam_load(self.x.ravel(), self.y.ravel(), self.d.ravel(), self.sig)
             return eng.beam_stats(0, sigcut=sigcut, do_abs=do_abs)

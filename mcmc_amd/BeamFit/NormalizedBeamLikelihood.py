@@ -38,7 +38,8 @@ class NormalizedBeamLikelihood(Likelihood.Likelihood):
 
     @property
     def engine(self):
-        key = (len(self.data), tuple(sorted((k, str(v)) for k, v in self.model.prior_state().items())))
+        key = (len(self.data), tuple(getattr(d, "version", 0) for d in self.data),
+               tuple(sorted((k, str(v)) for k, v in self.model.prior_state().items())))
         if self._eng is None or self._key != key:
             eng = Engine(device=self._device)
             self.load_into(eng)

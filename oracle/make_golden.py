@@ -1190,9 +1190,53 @@ def golden_writetab(R):
     print("writetab_g11.json: runs", sorted(out["runs"]))
 
 
+def golden_setup_sampler(R):
+    """G12: the beam driver's set-up, ProcessBeamData.setup_sampler (:124-216), run by the reference
+    module itself on a synthetic map: class-level prior state, start point, proposal widths.  The
+    module uses Python-2 implicit relative imports (`import MCMC`, `import Likelihood`, `from BeamFit
+    import ...`): the names are aliased to the package's own modules in sys.modules (no arithmetic
+    touched); its print() calls are silenced."""
+    import contextlib
+    import io
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import refbeam as RB                      # the synthetic map generator the tests use
+    sys.modules.setdefault("Likelihood", R["Likelihood"])
+    sys.modules.setdefault("BeamFit", importlib.import_module("MCMC.BeamFit"))
+    importlib.import_module("MCMC.BeamFit.NormalizedBeamModel")
+    sys.modules.setdefault("getdist", types.ModuleType("getdist"))
+    PBD = importlib.import_module("MCMC.BeamFit.ProcessBeamData")
+    BD = R["BeamFit.BeamData"]
+    mod = R["BeamFit.OffsetNormalizedBeamModel"].OffsetNormalizedBeamModel
+    cases = []
+    for seed, n, scale, smm in [(8, 64, None, (3, 8)), (21, 48, 0.8, (2, 6)), (5, 40, None, (3, 8))]:
+        x, y, d, noise, truth, prior = RB.synth_beam_maps(1, n=n, seed=seed)
+        abs_sum = float(np.abs(d[0]).sum())
+        data = BD.BeamData(x.copy(), y.copy(), d[0].copy(), noise)
+        with contextlib.redirect_stdout(io.StringIO()):
+            like, prop_sigmas, start = PBD.setup_sampler([data], data, useNormalizedBeam=True,
+                                                         rangeScale=scale, sigminmax=smm)
+        cases.append(dict(
+            seed=seed, n=n, rangeScale=scale, sigminmax=list(smm),
+            input_abs_sum=abs_sum, noise=float(noise),
+            centerMin=[float(v) for v in mod.centerMin], centerMax=[float(v) for v in mod.centerMax],
+            sigMin=float(mod.sigMin), sigMax=float(mod.sigMax),
+            paramBlocks=[int(v) for v in mod.paramBlocks], nBlock=int(mod.nBlock),
+            prop_sigmas=[float(v) for v in mod.unpackage(prop_sigmas)],
+            start=[float(v) for v in mod.unpackage(start)],
+            prior_at_start=float(mod.prior(*start)),
+            lnlike_at_start=float(like.lnLike(start))))
+    with open(os.path.join(OUT, "setup_sampler_g12.json"), "w") as f:
+        json.dump(dict(ref_sha=ref_tree_sha(), cases=cases), f, indent=0)
+    print("wrote setup_sampler_g12.json")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist", "beamfuncs", "writetab"]
+    which = sys.argv[1:] or ["sed", "cl", "beam", "readers", "clfiles", "getdist", "beamfuncs", "writetab",
+                             "setup_sampler"]
     R = load_reference()
     if "sed" in which:
         golden_sed(R)
@@ -1210,6 +1254,8 @@ def main():
         golden_beamfuncs(R)
     if "writetab" in which:
         golden_writetab(R)
+    if "setup_sampler" in which:
+        golden_setup_sampler(R)
 
 
 if __name__ == "__main__":

@@ -123,7 +123,8 @@ def synth_beam_maps(M, n=256, seed=3, noise=0.1, half=20.0):
 
 def beam_stats(m: BeamMap, sigcut=None, do_abs=False):
     """BeamData.stats, BeamData.py:35-71: data-weighted <x>, <y>, var x, var y.  (The reference
-    subtracts the mean from self.d in place, :52; this restatement leaves the map untouched.)"""
+    subtracts the mean from self.d in place, :45-52, so its later likelihood calls see the shifted
+    map; this function is pure - the product's BeamData.stats reproduces the shift, pinned by G12.)"""
     dd = np.abs(m.d) if do_abs else m.d.copy()
     dd = dd - dd.mean()
     if sigcut is not None:

@@ -84,11 +84,45 @@ def test_prior_of_the_plain_class():
 
 
 @pytest.mark.gpu
+def test_setup_sampler_matches_the_reference():
+    """G12 (tests/golden/setup_sampler_g12.json): the reference's own ProcessBeamData.setup_sampler
+    (:124-216; imported by oracle/make_golden.py with its Python-2 sibling imports aliased) on
+    synthetic maps - class-level prior state, start point, proposal widths, and the likelihood at
+    the start point - against the rebuilt driver over the device's BeamData.stats."""
+    from oracle import refbeam as RB
+    from mcmc_amd.BeamFit import OffsetNormalizedBeamModel as ONBM
+    from mcmc_amd.BeamFit import ProcessBeamData as PBD
+    from mcmc_amd.BeamFit.BeamData import BeamData
+    with open(os.path.join(HERE, "golden", "setup_sampler_g12.json")) as f:
+        g12 = json.load(f)
+    mod = ONBM.OffsetNormalizedBeamModel
+    saved = (mod.centerMin, mod.centerMax, mod.sigMin, mod.sigMax, mod.paramBlocks, mod.nBlock)
+    try:
+        for c in g12["cases"]:
+            x, y, d, noise, truth, prior = RB.synth_beam_maps(1, n=c["n"], seed=c["seed"])
+            assert float(np.abs(d[0]).sum()) == c["input_abs_sum"] and noise == c["noise"]
+            data = BeamData(x, y, d[0], noise)
+            like, prop_sigmas, start = PBD.setup_sampler([data], data, useNormalizedBeam=True,
+                                                         rangeScale=c["rangeScale"],
+                                                         sigminmax=tuple(c["sigminmax"]), verbose=False)
+            assert [float(v) for v in mod.centerMin] == c["centerMin"]
+            assert [float(v) for v in mod.centerMax] == c["centerMax"]
+            assert (float(mod.sigMin), float(mod.sigMax)) == (c["sigMin"], c["sigMax"])
+            assert list(mod.paramBlocks) == c["paramBlocks"] and mod.nBlock == c["nBlock"]
+            # the moments behind the start point are summed on the device: to rounding
+            np.testing.assert_allclose(np.asarray(mod.unpackage(start), float), c["start"], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(np.asarray(mod.unpackage(prop_sigmas), float), c["prop_sigmas"], rtol=1e-12)
+            assert mod.prior(*start) == c["prior_at_start"]
+            lp = like.lnLike(start)
+            assert abs(lp - c["lnlike_at_start"]) <= 1e-11 * abs(c["lnlike_at_start"])
+    finally:
+        (mod.centerMin, mod.centerMax, mod.sigMin, mod.sigMax, mod.paramBlocks, mod.nBlock) = saved
+
+
+@pytest.mark.gpu
 def test_setup_sampler_and_sample1beam():
-    """The beam driver end to end.  setup_sampler's start point and proposal widths against a
-    NumPy restatement of ProcessBeamData.py:149-216 on the oracle's BeamData.stats (the reference
-    module itself cannot be imported - bare `import MCMC` - so this function is parity unpinned
-    beyond that restatement); sample1beam recovers the map's parameters."""
+    """The beam driver end to end: setup_sampler (pinned by G12 above; here its pieces against the
+    oracle's BeamData.stats), then sample1beam recovers the map's parameters."""
     from oracle import refbeam as RB
     from mcmc_amd.BeamFit import OffsetNormalizedBeamModel as ONBM
     from mcmc_amd.BeamFit import ProcessBeamData as PBD
