@@ -601,6 +601,9 @@ def test_sed_abi_errors_leave_the_context_usable():
     with Engine() as e:
         with pytest.raises(Mi355Error, match="not initialised"):
             e.mh_run(10)                                                        # nothing loaded yet
+        assert e.sed_fast_sources == -1 and e.mh_lane_group == -1               # nothing to report on yet
+        with pytest.raises(Mi355Error, match="lane map"):
+            e.mh_set_lane_map(3)
         with pytest.raises(Mi355Error, match="outside"):
             e.sed_load(R.M2N, np.array([8, 9], np.int32), nu, d, sig)          # nb > nb_max
         bad = nu.copy()
