@@ -296,6 +296,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
   }
   __syncthreads();
 
+  // per-slot constants of the thread's parameters (block, rank in the block, prior type) in registers:
+  // three dependent LDS lookups fewer on the proposal's latency chain
+  int rblk[MS], rrank[MS], rtype[MS];
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    const int i = grp + G * m;
+    rblk[m] = i < P ? block_of[i] : -1;
+    rrank[m] = i < P ? rank_of[i] : 0;
+    rtype[m] = i < P ? cltype[i] : 1;
+  }
   const bool inject = g.inj_n != nullptr;
   const double* e2t = kExp2Table;                          // accept test: as k_gmh_accept
   int blk = g.blk;
@@ -341,13 +351,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
         const int i = grp + G * m;
         if (i < P) {
           double v = rth[m];
-          if (in_block(i)) {                               // :151, :156-159
-            const double zi = valid ? (inject ? ldas<1>(inj + i) : zrow[rank_of[i] * CB]) : 0.0;
+          if (g.nblock == 0 || rblk[m] == blk) {           // :151, :156-159
+            const double zi = valid ? (inject ? ldas<1>(inj + i) : zrow[rrank[m] * CB]) : 0.0;
             v += zi * rsg[m];
           }
           rnew[m] = v;
           thn[i * CB + cl] = v;
-          if (cltype[i] != 1 && v < 0) pbad[cl] = 1;
+          if (rtype[m] != 1 && v < 0) pbad[cl] = 1;
         }
       }
     } else {
