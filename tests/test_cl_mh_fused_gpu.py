@@ -45,6 +45,16 @@ def problem(kind):
     if kind == "p32":                                     # 32 bins: the largest co-moment triangle kept in registers
         model, d, truth = RC.synth_cl_problem(nb=64, npar=32, calib=0.0, beam=0.0, lmax=2000, seed=14)
         return model, [d], truth
+    if kind == "densek":                                  # every band's window spans every bin: K is dense
+        model, d, truth = RC.synth_cl_problem(nb=40, npar=12, calib=0.0, beam=0.0, lmax=900, seed=15)
+        rng = np.random.default_rng(2)
+        L = d.window.shape[2]
+        w = d.window.copy()
+        ell = np.arange(L, dtype=np.float64)
+        for i in range(w.shape[0]):                       # broad smooth windows on top of the top hats
+            w[i, 0, 2:] += 1e-3 * (1 + 0.3 * np.sin(ell[2:] / (7.0 + i))) * rng.uniform(0.5, 1.5)
+        d2 = dataclasses.replace(d, window=w, win_min=np.full(w.shape[0], 2), win_max=np.full(w.shape[0], L - 1))
+        return model, [d2], truth
     raise ValueError(kind)
 
 
@@ -102,7 +112,7 @@ def same(a, b):
             assert np.array_equal(x, y, equal_nan=True), k
 
 
-@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96"])
+@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96", "densek"])
 def test_fused_equals_stepwise_every_likelihood_shape(kind):
     C = 40 if kind != "sym144" else 19                    # not a multiple of the 16 chains of a block
     same(run(kind, True, "uncorr_block", C, False), run(kind, False, "uncorr_block", C, False))
@@ -130,6 +140,22 @@ def test_fused_equals_stepwise_with_injected_draws():
     for mode in ("uncorr_block", "corr_all", "rotate_block"):
         same(run("calib11", True, mode, C, False, inject=(zn, zu)),
              run("calib11", False, mode, C, False, inject=(zn, zu)))
+
+
+def test_dense_k_band_powers_match_the_oracle():
+    """The compact K of the fused sampler and the k-step ranges of the batched band-power kernel on a
+    data set whose windows meet every bin (no zero k-step to skip): lnL against the oracle."""
+    from oracle import refcl as RC
+    from mcmc_amd import Engine
+    model, data, truth = problem("densek")
+    rng = np.random.default_rng(6)
+    q = truth[None, :] * rng.uniform(0.9, 1.1, (24, model.nparam))
+    with Engine(seed=1) as eng:
+        eng.cl_load(data)
+        eng.cl_set_binning(model.bins, model.shapefun)
+        got = eng.cl_lnlike(q)
+    ref = np.array([RC.cl_lnlike(qq, model, data) for qq in q])
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
 
 
 def test_problems_beyond_the_fused_kernel_fall_back_to_the_stepwise_engine():
