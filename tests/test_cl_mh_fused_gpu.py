@@ -45,6 +45,9 @@ def problem(kind):
     if kind == "p32":                                     # 32 bins: the largest co-moment triangle kept in registers
         model, d, truth = RC.synth_cl_problem(nb=64, npar=32, calib=0.0, beam=0.0, lmax=2000, seed=14)
         return model, [d], truth
+    if kind == "big384":                                  # 24 column tiles, 11-point beam grid: the tables
+        model, d, truth = RC.synth_cl_problem(nb=384, npar=40, calib=0.0, beam=0.02, lmax=4000, seed=16)
+        return model, [d], truth                          # do not fit in LDS - the generic kernel serves it
     if kind == "densek":                                  # every band's window spans every bin: K is dense
         model, d, truth = RC.synth_cl_problem(nb=40, npar=12, calib=0.0, beam=0.0, lmax=900, seed=15)
         rng = np.random.default_rng(2)
@@ -112,9 +115,9 @@ def same(a, b):
             assert np.array_equal(x, y, equal_nan=True), k
 
 
-@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96", "densek"])
+@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96", "densek", "big384"])
 def test_fused_equals_stepwise_every_likelihood_shape(kind):
-    C = 40 if kind != "sym144" else 19                    # not a multiple of the 16 chains of a block
+    C = 40 if kind not in ("sym144", "big384") else 19    # not a multiple of the 16 chains of a block
     same(run(kind, True, "uncorr_block", C, False), run(kind, False, "uncorr_block", C, False))
 
 
