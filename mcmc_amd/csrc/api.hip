@@ -128,13 +128,15 @@ static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c-
 // give every SIMD of the GPU a wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has
 // the crossover there, 2.4x (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
 // mi355_mh_set_lane_map overrides (tests hold the two mappings to identical chains).
-static int sed_lane_group(const mi355_ctx* c) {
+static int sed_lane_group(const mi355_ctx* c, bool ext = false) {
   if (c->lane_map == 1 || !sed_all_fast(c) || c->model.model == MI355_SED_M2) return 1;
   const int g = c->nb_most <= 8 ? 8 : (c->nb_most <= 32 ? 32 : 0);
   if (g == 0 || c->nb_most < 2) return 1;
   size_t lds = 0;
   const int bs = pick_block(c->C, c->nbm, c->S, &lds);
-  if (bs <= 0 || lds + 16 + static_cast<size_t>(bs) * sizeof(double2) > kLdsLimit) return 1;   // exchange slots
+  if (bs <= 0) return 1;
+  if (ext) lds += static_cast<size_t>(c->P * (c->P + 1) / 2) * bs * sizeof(double);   // the sqrt matrices
+  if (lds + 16 + static_cast<size_t>(bs) * sizeof(double2) > kLdsLimit) return 1;     // exchange slots
   if (c->lane_map == 2) return g;
   return c->N * g <= 65536 ? g : 1;
 }
@@ -204,7 +206,19 @@ struct LaunchRun {
       const size_t lds_ext = lds + static_cast<size_t>(ntri) * bs * sizeof(double);
       MI355_REQUIRE(sed_all_fast(c) && lds_ext <= kLdsLimit,
                     "the extended fused sampler does not serve this catalogue (step-wise engine only)");
-      hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+      const int G = sed_lane_group(c, true);
+      const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, bs / (G > 0 ? G : 1)));
+      const size_t lds_g = lds_ext + 16 + static_cast<size_t>(bs) * sizeof(double2);
+      if constexpr (M != MI355_SED_M2) {
+        if (G == 8)
+          hipLaunchKernelGGL((k_mh_run<M, true, true, 8>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        else if (G == 32)
+          hipLaunchKernelGGL((k_mh_run<M, true, true, 32>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        else
+          hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+      } else {
+        hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+      }
     } else if (sed_all_fast(c)) {
       const int G = sed_lane_group(c);
       const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, bs / (G > 0 ? G : 1)));
@@ -320,7 +334,13 @@ int mi355_init(int device, uint64_t seed, mi355_ctx** out) {
   c->device = device;
   c->seed = seed;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    // the side stream of mixed catalogues: highest priority, so that it gets a hardware queue of its
+    // own (streams of equal priority may share one and serialise) and its few long blocks start first
+    int prio_lo = 0, prio_hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi);
+  }
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

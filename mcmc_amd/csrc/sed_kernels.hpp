@@ -259,11 +259,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // machine once there are chains enough for it.  8 / 32: lanes = (chain, band), G lanes hold copies of
 // one chain and each evaluates one band (sed_lnlike_fast_cb; lane 0 of the group writes the chain's
 // state) - north_star's primary mapping, which the host picks for jobs too small to give every SIMD
-// a wave (sed_lane_group in api.hip).  Same draws, same arithmetic in the same order: the chains are
-// identical bit for bit under either mapping (tests/test_sed_gpu.py).
+// a wave (sed_lane_group in api.hip), for the plain and the extended sampler alike.  Same draws, same
+// arithmetic in the same order: the chains are identical bit for bit under either mapping
+// (tests/test_sed_gpu.py, tests/test_gmh_gpu.py).
 template <int MODEL, bool FAST, bool EXT = false, int G = 1>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
-  static_assert(G == 1 || (FAST && !EXT), "(chain, band) lanes: fast path, uncorrelated proposals");
+  static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -313,7 +314,10 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   // EXT: this chain's sqrt matrix, lower triangle row by row, in the lane's LDS column
   double* Ll = smem + static_cast<size_t>(nsrc) * stride + threadIdx.x;
   // G > 1: the lane's 16-byte slot of the band-term exchange, behind the band tables
-  double2* cb_slot = reinterpret_cast<double2*>(smem + ((static_cast<size_t>(nsrc) * stride + 1) & ~static_cast<size_t>(1))) + threadIdx.x;
+  // (behind the sqrt matrices in the extended instantiation)
+  double2* cb_slot = reinterpret_cast<double2*>(
+                         smem + ((static_cast<size_t>(nsrc) * stride + (EXT ? static_cast<size_t>(NTRI) * blockDim.x : 0) + 1) &
+                                 ~static_cast<size_t>(1))) + threadIdx.x;
   if constexpr (EXT) {
     if (a.mode != 0) {
 #pragma unroll
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       m2[i] = fma(dlt, th[i] - mu[i], m2[i]);
     }
     if constexpr (EXT) {
-      if (a.comom != nullptr) {                            // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
+      if (a.comom != nullptr && writer) {                  // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
         const double cf = 1.0 - rn;
         double cur[NTRI];
 #pragma unroll

@@ -343,11 +343,13 @@ def test_graph_replay_survives_scratch_regrowth(kind):
 @pytest.mark.parametrize("model,mode", [("M2N", "uncorr_block"), ("M2N", "corr_all"), ("M2N", "corr_block"),
                                         ("M2N", "rotate_block"), ("M1N_LOGA", "corr_all"),
                                         ("THICK", "rotate_block")])
-def test_sed_fused_extended_kernel_equals_stepwise_engine(model, mode):
+@pytest.mark.parametrize("lane_map", [1, 2])
+def test_sed_fused_extended_kernel_equals_stepwise_engine(model, mode, lane_map):
     """Chains started by mi355_mh_init_problem on a SED catalogue: the fused kernel's extended
-    instantiation (correlated / rotated proposals, co-moments; one launch per run) against the
-    launch-per-step engine - same draws, same arithmetic, identical chains, covariance, adapted
-    widths and sqrt matrices; free-running and with injected draws."""
+    instantiation (correlated / rotated proposals, co-moments; one launch per run) - under both
+    lane mappings, lane = chain and lanes = (chain, band) - against the launch-per-step engine:
+    same draws, same arithmetic, identical chains, covariance, adapted widths and sqrt matrices;
+    free-running and with injected draws."""
     from mcmc_amd import Engine, synth
     S, C = 5, 37
     nu, d, sig, truth = synth.sed_catalogue(S, seed=3)
@@ -367,6 +369,7 @@ def test_sed_fused_extended_kernel_equals_stepwise_engine(model, mode):
         out = {}
         with Engine(seed=99) as eng:
             eng.mh_set_fused(fused)
+            eng.mh_set_lane_map(lane_map)
             eng.sed_load(model, nb, nu, d, sig)
             eng.mh_init_problem("sed", C, start, sg0, param_blocks=np.arange(P) if block else None,
                                 randomize_start=True, track_cov=True)
