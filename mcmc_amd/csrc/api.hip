@@ -123,22 +123,41 @@ struct LaunchStart {
 // engine, source by source).
 static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c->nslow == 0; }
 
-// Lanes per chain of the next plain k_mh_run launch (uncorrelated proposals, whole catalogue on the
-// fast path): 1 = lane per chain; 8 / 32 = lanes (chain, band), picked when the job is too small to
-// give every SIMD of the GPU a wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has
-// the crossover there, 2.4x (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
-// mi355_mh_set_lane_map overrides (tests hold the two mappings to identical chains).
-static int sed_lane_group(const mi355_ctx* c, bool ext = false) {
-  if (c->lane_map == 1 || !sed_all_fast(c) || c->model.model == MI355_SED_M2) return 1;
-  const int g = c->nb_most <= 8 ? 8 : (c->nb_most <= 32 ? 32 : 0);
-  if (g == 0 || c->nb_most < 2) return 1;
+// Block size and lanes per chain of the next k_mh_run launch (ext: its extended instantiation, which
+// keeps a sqrt matrix per lane in LDS).  Lanes per chain: 1 = lane per chain; 8 / 32 = lanes (chain,
+// band), picked when the whole catalogue is on the fast path and the job is too small to give every
+// SIMD of the GPU a wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has the
+// crossover there, 3x (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
+// mi355_mh_set_lane_map overrides (tests hold the two mappings to identical chains).  The block is
+// the largest of 256 / 128 / 64 lanes whose band tables, per-lane extras and exchange slots fit.
+struct SedPlan {
+  int bs = 0;
   size_t lds = 0;
-  const int bs = pick_block(c->C, c->nbm, c->S, &lds);
-  if (bs <= 0) return 1;
-  if (ext) lds += static_cast<size_t>(c->P * (c->P + 1) / 2) * bs * sizeof(double);   // the sqrt matrices
-  if (lds + 16 + static_cast<size_t>(bs) * sizeof(double2) > kLdsLimit) return 1;     // exchange slots
-  if (c->lane_map == 2) return g;
-  return c->N * g <= 65536 ? g : 1;
+  int G = 1;
+};
+static int pick_block_x(const mi355_ctx* c, size_t per_lane, size_t fixed, size_t* lds) {
+  for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
+    *lds = lds_bytes(bs, c->C, c->nbm, c->S) + per_lane * bs + fixed;
+    if (*lds <= kLdsLimit) return bs;
+  }
+  return 0;
+}
+static SedPlan sed_plan(const mi355_ctx* c, bool ext) {
+  SedPlan p;
+  const size_t per_lane = ext ? static_cast<size_t>(c->P * (c->P + 1) / 2) * sizeof(double) : 0;
+  p.bs = pick_block_x(c, per_lane, 0, &p.lds);
+  if (c->lane_map == 1 || !sed_all_fast(c) || c->model.model == MI355_SED_M2) return p;
+  const int g = c->nb_most <= 8 ? 8 : (c->nb_most <= 32 ? 32 : 0);
+  if (g == 0 || c->nb_most < 2) return p;
+  if (c->lane_map != 2 && c->N * g > 65536) return p;
+  size_t lds = 0;
+  const int bs = pick_block_x(c, per_lane + sizeof(double2), 16, &lds);   // + the exchange slots
+  if (bs > 0) {
+    p.bs = bs;
+    p.lds = lds;
+    p.G = g;
+  }
+  return p;
 }
 
 // Lists of the chain blocks (bs chains each) whose sources are all fast / not all fast.
@@ -201,33 +220,30 @@ struct LaunchRun {
       }
     }
     if (a.mode != 0 || a.comom != nullptr) {
-      // extended sampler: correlated / rotated proposals, co-moments (sed_mh_fused_ok checked it fits)
-      constexpr int ntri = ModelTraits<M>::P * (ModelTraits<M>::P + 1) / 2;
-      const size_t lds_ext = lds + static_cast<size_t>(ntri) * bs * sizeof(double);
-      MI355_REQUIRE(sed_all_fast(c) && lds_ext <= kLdsLimit,
+      // extended sampler: correlated / rotated proposals, co-moments (sed_mh_fused_ok checked it fits);
+      // its own block size: the per-lane sqrt matrices count against LDS
+      const SedPlan pe = sed_plan(c, true);
+      MI355_REQUIRE(sed_all_fast(c) && pe.bs > 0,
                     "the extended fused sampler does not serve this catalogue (step-wise engine only)");
-      const int G = sed_lane_group(c, true);
-      const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, bs / (G > 0 ? G : 1)));
-      const size_t lds_g = lds_ext + 16 + static_cast<size_t>(bs) * sizeof(double2);
+      const unsigned grid_e = static_cast<unsigned>(ceil_div(c->N, pe.bs / pe.G));
       if constexpr (M != MI355_SED_M2) {
-        if (G == 8)
-          hipLaunchKernelGGL((k_mh_run<M, true, true, 8>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
-        else if (G == 32)
-          hipLaunchKernelGGL((k_mh_run<M, true, true, 32>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        if (pe.G == 8)
+          hipLaunchKernelGGL((k_mh_run<M, true, true, 8>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
+        else if (pe.G == 32)
+          hipLaunchKernelGGL((k_mh_run<M, true, true, 32>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
         else
-          hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+          hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
       } else {
-        hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid), dim3(bs), lds_ext, c->stream, a);
+        hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
       }
     } else if (sed_all_fast(c)) {
-      const int G = sed_lane_group(c);
-      const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, bs / (G > 0 ? G : 1)));
+      const SedPlan pp = sed_plan(c, false);
+      const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, pp.bs / pp.G));
       if constexpr (M != MI355_SED_M2) {
-        const size_t lds_g = lds + 16 + static_cast<size_t>(bs) * sizeof(double2);   // + the exchange slots
-        if (G == 8)
-          hipLaunchKernelGGL((k_mh_run<M, true, false, 8>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
-        else if (G == 32)
-          hipLaunchKernelGGL((k_mh_run<M, true, false, 32>), dim3(grid_g), dim3(bs), lds_g, c->stream, a);
+        if (pp.G == 8)
+          hipLaunchKernelGGL((k_mh_run<M, true, false, 8>), dim3(grid_g), dim3(pp.bs), pp.lds, c->stream, a);
+        else if (pp.G == 32)
+          hipLaunchKernelGGL((k_mh_run<M, true, false, 32>), dim3(grid_g), dim3(pp.bs), pp.lds, c->stream, a);
         else
           hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
       } else {
@@ -708,9 +724,7 @@ namespace mi355 {
 // LDS for the band tables plus the per-lane sqrt matrix.
 bool sed_mh_fused_ok(const mi355_ctx* c) {
   if (!c || !c->sed_loaded || !sed_all_fast(c) || c->P > kMaxParam) return false;
-  size_t lds = 0;
-  const int bs = pick_block(c->C, c->nbm, c->S, &lds);
-  return bs > 0 && lds + static_cast<size_t>(c->P * (c->P + 1) / 2) * bs * sizeof(double) <= kLdsLimit;
+  return sed_plan(c, true).bs > 0;
 }
 }  // namespace mi355
 
@@ -784,7 +798,7 @@ int mi355_mh_set_lane_map(mi355_ctx* c, int32_t mode) {
 int mi355_mh_lane_group(mi355_ctx* c) {
   if (!c || !c->mh_ready || gmh_active(c)) return -1;
   if (incremental_applies(c)) return 1;
-  return sed_lane_group(c);
+  return sed_plan(c, false).G;
 }
 
 int64_t mi355_sed_fast_sources(mi355_ctx* c) {

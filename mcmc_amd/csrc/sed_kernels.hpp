@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // machine once there are chains enough for it.  8 / 32: lanes = (chain, band), G lanes hold copies of
 // one chain and each evaluates one band (sed_lnlike_fast_cb; lane 0 of the group writes the chain's
 // state) - north_star's primary mapping, which the host picks for jobs too small to give every SIMD
-// a wave (sed_lane_group in api.hip), for the plain and the extended sampler alike.  Same draws, same
+// a wave (sed_plan in api.hip), for the plain and the extended sampler alike.  Same draws, same
 // arithmetic in the same order: the chains are identical bit for bit under either mapping
 // (tests/test_sed_gpu.py, tests/test_gmh_gpu.py).
 template <int MODEL, bool FAST, bool EXT = false, int G = 1>

@@ -340,6 +340,41 @@ def test_graph_replay_survives_scratch_regrowth(kind):
         assert np.array_equal(res[0][key], res[1][key]), key
 
 
+@pytest.mark.parametrize("lane_map", [1, 2])
+def test_sed_extended_kernel_sizes_its_block_to_lds(lane_map):
+    """16 chains per source and 27 bands: 17 band tables per 256-lane block plus a sqrt matrix per lane
+    do not fit in LDS - the extended sampler then runs with a smaller block instead of leaving the
+    job to the launch-per-step engine (31 against 8 / 4 us per step), and still equals it."""
+    from mcmc_amd import Engine, synth
+    S, C, P = 16, 16, 6
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=4, nb=27)
+    nb = np.full(S, 27, np.int32)
+    nb[3] = 20
+    rng = np.random.default_rng(9)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T + P * np.eye(P)
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    res = []
+    for fused in (True, False):
+        with Engine(seed=7) as eng:
+            eng.mh_set_fused(fused)
+            eng.mh_set_lane_map(lane_map)
+            eng.sed_load("M2N", nb, nu, d, sig)
+            eng.mh_init_problem("sed", C, truth[:, None, :].repeat(C, axis=1), np.full(P, 0.02), param_blocks=None,
+                                randomize_start=False, track_cov=True)
+            assert eng.mh_fused_active == fused
+            eng.mh_set_sqrt_matrix(L)
+            eng.mh_run(70, thin=1)
+            res.append((eng.mh_trace(), eng.mh_moments(), eng.mh_covar(normalized=False)))
+    for x, y in zip(res[0][0], res[1][0]):
+        assert np.array_equal(x, y, equal_nan=True)
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k], equal_nan=True), k
+    for x, y in zip(res[0][2], res[1][2]):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize("model,mode", [("M2N", "uncorr_block"), ("M2N", "corr_all"), ("M2N", "corr_block"),
                                         ("M2N", "rotate_block"), ("M1N_LOGA", "corr_all"),
                                         ("THICK", "rotate_block")])
