@@ -30,6 +30,7 @@ static __device__ __align__(256) double scratch[3 * MI355_RHAT_NOALLOC_MAX];
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+constexpr size_t kLdsBig = 128 * 1024;   // dynamic LDS of a block whose kernel has been opted in (launch_lds); 160 KB per CU
 constexpr size_t kLdsLimit = 64 * 1024 - kExp2Entries * sizeof(double);   // dynamic LDS a block may ask for without opt-in (static: the 16 KB 2^y table)
 
 // LDS bytes a `bs`-chain block needs for the band tables of the sources it can touch
@@ -39,12 +40,26 @@ static size_t lds_bytes(int bs, int C, int nbm, int64_t nsources) {
   return static_cast<size_t>(per_block) * kBandFields * nbm * sizeof(double);
 }
 
-// Largest block (256/128/64 chains) whose band tables fit in LDS; 0 if none does.
+// Largest block (256/128/64 chains) whose band tables fit in LDS; 0 if none does.  First within what
+// a kernel may ask for without opting in (kLdsLimit: several blocks per CU), then within kLdsBig
+// (many bands and few chains per source: 64 sources of 27 bands are 110 KB) - launch_lds opts the
+// kernel in.
 static int pick_block(int C, int nbm, int64_t nsources, size_t* lds) {
-  for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
-    *lds = lds_bytes(bs, C, nbm, nsources);
-    if (*lds <= kLdsLimit) return bs;
-  }
+  for (size_t limit : {kLdsLimit, kLdsBig})
+    for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
+      *lds = lds_bytes(bs, C, nbm, nsources);
+      if (*lds <= limit) return bs;
+    }
+  return 0;
+}
+
+// Launch with `lds` bytes of dynamic LDS, raising the kernel's limit first where it is needed.
+template <typename Kern, typename... Args>
+static int launch_lds(Kern kern, unsigned grid, int bs, size_t lds, hipStream_t stream, Args... args) {
+  if (lds > kLdsLimit)
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds)));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(bs), lds, stream, args...);
   return 0;
 }
 
@@ -73,8 +88,8 @@ struct LaunchLnlike {
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, C);
     const unsigned grid = static_cast<unsigned>(ceil_div(n_eval, bs));
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k_sed_lnlike<M>, dim3(grid), dim3(bs), lds, c->stream, c->bands.p,
-                       c->nb.p, c->nbm, s0, n_eval, C, theta, lnl, derived, c->kc);
+    { if (launch_lds(k_sed_lnlike<M>, grid, bs, lds, c->stream, c->bands.p,
+                       c->nb.p, c->nbm, s0, n_eval, C, theta, lnl, derived, c->kc)) return -2; }
     MI355_HIP(hipGetLastError());
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
     if (!c->capturing) c->ev_valid = true;
@@ -112,7 +127,7 @@ struct LaunchStart {
     const int bs = pick_block(c->C, c->nbm, c->S, &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
-    hipLaunchKernelGGL(k_mh_start<M>, dim3(grid), dim3(bs), lds, c->stream, a);
+    { if (launch_lds(k_mh_start<M>, grid, bs, lds, c->stream, a)) return -2; }
     MI355_HIP(hipGetLastError());
     return 0;
   }
@@ -136,10 +151,11 @@ struct SedPlan {
   int G = 1;
 };
 static int pick_block_x(const mi355_ctx* c, size_t per_lane, size_t fixed, size_t* lds) {
-  for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
-    *lds = lds_bytes(bs, c->C, c->nbm, c->S) + per_lane * bs + fixed;
-    if (*lds <= kLdsLimit) return bs;
-  }
+  for (size_t limit : {kLdsLimit, kLdsBig})
+    for (int bs = kBlockThreads; bs >= 64; bs >>= 1) {
+      *lds = lds_bytes(bs, c->C, c->nbm, c->S) + per_lane * bs + fixed;
+      if (*lds <= limit) return bs;
+    }
   return 0;
 }
 static SedPlan sed_plan(const mi355_ctx* c, bool ext) {
@@ -212,7 +228,7 @@ struct LaunchRun {
     if constexpr (M == MI355_SED_M2N || M == MI355_SED_M2N_LOGA) {
       const size_t lds_inc = lds + 2 * static_cast<size_t>(kIncBands) * bs * sizeof(double);
       if (incremental_applies(c) && lds_inc <= kLdsLimit) {
-        hipLaunchKernelGGL(k_mh_run_inc<M>, dim3(grid), dim3(bs), lds_inc, c->stream, a);
+        { if (launch_lds(k_mh_run_inc<M>, grid, bs, lds_inc, c->stream, a)) return -2; }
         MI355_HIP(hipGetLastError());
         if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
         if (!c->capturing) c->ev_valid = true;
@@ -228,29 +244,29 @@ struct LaunchRun {
       const unsigned grid_e = static_cast<unsigned>(ceil_div(c->N, pe.bs / pe.G));
       if constexpr (M != MI355_SED_M2) {
         if (pe.G == 8)
-          hipLaunchKernelGGL((k_mh_run<M, true, true, 8>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true, true, 8>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }
         else if (pe.G == 32)
-          hipLaunchKernelGGL((k_mh_run<M, true, true, 32>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true, true, 32>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }
         else
-          hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true, true>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }
       } else {
-        hipLaunchKernelGGL((k_mh_run<M, true, true>), dim3(grid_e), dim3(pe.bs), pe.lds, c->stream, a);
+        { if (launch_lds((k_mh_run<M, true, true>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }
       }
     } else if (sed_all_fast(c)) {
       const SedPlan pp = sed_plan(c, false);
       const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, pp.bs / pp.G));
       if constexpr (M != MI355_SED_M2) {
         if (pp.G == 8)
-          hipLaunchKernelGGL((k_mh_run<M, true, false, 8>), dim3(grid_g), dim3(pp.bs), pp.lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true, false, 8>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
         else if (pp.G == 32)
-          hipLaunchKernelGGL((k_mh_run<M, true, false, 32>), dim3(grid_g), dim3(pp.bs), pp.lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true, false, 32>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
         else
-          hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
+          { if (launch_lds((k_mh_run<M, true>), grid, bs, lds, c->stream, a)) return -2; }
       } else {
-        hipLaunchKernelGGL((k_mh_run<M, true>), dim3(grid), dim3(bs), lds, c->stream, a);
+        { if (launch_lds((k_mh_run<M, true>), grid, bs, lds, c->stream, a)) return -2; }
       }
     } else if (c->kc.fast_ok == 0.0)
-      hipLaunchKernelGGL((k_mh_run<M, false>), dim3(grid), dim3(bs), lds, c->stream, a);
+      { if (launch_lds((k_mh_run<M, false>), grid, bs, lds, c->stream, a)) return -2; }
     else {
       // mixed catalogue: the blocks with a source outside the fast domain on stream2 (each lane
       // follows its own source there), all the others through the fast instantiation beside them
@@ -259,13 +275,11 @@ struct LaunchRun {
       as.blocklist = c->blk_slow.p;
       MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
       MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-      hipLaunchKernelGGL((k_mh_run<M, false>), dim3(static_cast<unsigned>(c->nblk_slow)), dim3(bs), lds,
-                         c->stream2, as);
+      { if (launch_lds((k_mh_run<M, false>), static_cast<unsigned>(c->nblk_slow), bs, lds, c->stream2, as)) return -2; }
       MI355_HIP(hipGetLastError());
       MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
       if (c->nblk_fast > 0)
-        hipLaunchKernelGGL((k_mh_run<M, true>), dim3(static_cast<unsigned>(c->nblk_fast)), dim3(bs), lds,
-                           c->stream, af);
+        { if (launch_lds((k_mh_run<M, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
       MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     MI355_HIP(hipGetLastError());
@@ -443,7 +457,7 @@ int mi355_sed_load(mi355_ctx* c, const mi355_sed_model* m, int64_t S, int32_t nb
                 m->model, kModelNParam[m->model], m->nparam);
   MI355_REQUIRE(S > 0 && nb_max > 0, "mi355_sed_load: empty catalogue (S=%lld, nb_max=%d)",
                 static_cast<long long>(S), nb_max);
-  MI355_REQUIRE(static_cast<size_t>(nb_max) * kBandFields * sizeof(double) <= kLdsLimit,
+  MI355_REQUIRE(static_cast<size_t>(nb_max) * kBandFields * sizeof(double) <= kLdsBig,
                 "nb_max=%d too large for the LDS band tables", nb_max);
   for (int64_t s = 0; s < S; ++s)
     MI355_REQUIRE(nb[s] >= 0 && nb[s] <= nb_max, "nb[%lld]=%d outside [0,%d]",

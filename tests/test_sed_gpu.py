@@ -566,6 +566,40 @@ def test_lane_mappings_give_identical_chains(mid, nbands, G):
     assert out[1][0][2].mean() > 0.05                     # the chains did move
 
 
+@pytest.mark.parametrize("lane_map", [1, 2])
+def test_many_bands_one_chain_per_source(lane_map):
+    """One chain per source (the reference's own layout: one MCMC object per catalogue entry) with
+    27 bands: 64 band tables per block are 110 KB of LDS - the kernels opt in to it instead of
+    refusing the catalogue.  Likelihood batch, start, free-running chains against the oracle."""
+    from mcmc_amd import Engine
+    S, C, P, nsteps = 150, 1, 6, 40
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=41, nb=27)
+    nb = np.full(S, 27, np.int32)
+    nb[::7] = 19
+    rng = np.random.default_rng(3)
+    th = truth[:, None, :] * rng.uniform(0.9, 1.1, (S, C, P))
+    with Engine(seed=5) as e:
+        e.mh_set_lane_map(lane_map)
+        e.sed_load(R.M2N, nb, nu, d, sig)
+        got = e.sed_lnlike(th)
+        ref = np.array([[R.sed_lnlike(R.M2N, th[s, 0], R.GaussData(nu[s, :nb[s]], d[s, :nb[s]], sig[s, :nb[s]]))]
+                        for s in range(S)])
+        assert_lnl_close(got, ref, RTOL_LNL, "27 bands, one chain per source")
+        e.mh_init(C, truth[:, None, :], np.full(P, 0.02), param_blocks=np.arange(P), randomize_start=False)
+        z, u = e.rng_dump(e.step_total, nsteps, S * C, 1)
+        e.mh_run(nsteps, thin=1)
+        tr, lp, _ = e.mh_trace()
+    for s in (0, 7, 93, 149):
+        zz = np.zeros((nsteps, P))
+        for t in range(nsteps):
+            zz[t, t % P] = z[t, s, 0]
+        ch = R.Chain(R.sed_problem(R.M2N, R.GaussData(nu[s, :nb[s]], d[s, :nb[s]], sig[s, :nb[s]])), np.full(P, 0.02),
+                     truth[s], R.InjectedDraws(zz, u[:, s]), do_block=True, randomize_start=False)
+        ch.run(nsteps)
+        np.testing.assert_allclose(tr[:, s, 0], np.asarray(ch.samples)[1:], rtol=1e-12)
+        np.testing.assert_allclose(lp[:, s, 0], np.asarray(ch.lnPr)[1:], rtol=1e-11)
+
+
 def test_lane_mapping_is_picked_by_job_size():
     """Automatic choice: (chain, band) while chains x G fit one wave per SIMD, lane = chain beyond;
     lane = chain wherever the band-parallel kernel does not apply."""
