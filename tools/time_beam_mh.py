@@ -7,7 +7,6 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from mcmc_amd import Engine          # noqa: E402
-from mcmc_amd import synth           # noqa: E402
 
 
 def maps(M, side, seed=3):
