@@ -55,10 +55,10 @@ struct ClFormArgs {
   double* out;             // MARGE: chisq[rows]; TRIPLE: G[n][9]
 };
 
-// Row stride (doubles) of the matrices in HBM (K, N^-1 and its symmetrised copy): nbp + 16.  With a
-// stride of nbp = 256 doubles (2 KB = 16 cache lines) every row of a column tile starts on the same
-// L2 channel, and the blocks of the fused Metropolis-Hastings kernel - all reading the same tile at
-// the same time - queue on it (measured: band powers 13.9k -> see profiles/r2_clmh_summary.txt).
+// Row stride (doubles) of the matrices in HBM (K, N^-1 and its symmetrised copy): nbp + 16, so that
+// the rows of a column tile do not all start on the same L2 channel when nbp is a multiple of 256
+// doubles (2 KB = 16 cache lines).  Measured: no difference for the kernels here (the L2 hashes its
+// channels); kept because it costs nothing.
 __host__ __device__ inline int cl_gstride(int nbp) { return nbp + 16; }
 
 // (chain, sub-index) of global row `grow`: sub = marginalisation point (MARGE), row type
