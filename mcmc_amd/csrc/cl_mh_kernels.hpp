@@ -24,11 +24,12 @@
 // co-moments), else the matrix is streamed from L2 and two blocks share a CU.  Several data sets,
 // or tables that do not fit: the generic kernel (FORM = CLMH_ANY), everything from L2.
 //
-// Measured (MI355X, 4096 chains, nb = 64, 32 bins; profiles/r2_clmh_summary.txt): a step is a
-// chain of dependent LDS / MFMA / barrier latencies with one wave per SIMD - about 1250
-// instructions and 15 600 cycles per wave and step; halving the chains per block to double the
-// blocks per CU was measured and lost (10.9 vs 8.9 us per step: the idle tile rows cost more
-// than the overlap wins).
+// Measured (MI355X, 4096 chains, nb = 64, 32 bins; profiles/r2_clmh_summary.txt): 6.5 us per step
+// of all chains (step-wise engine: 35); a step is a chain of dependent LDS / MFMA / barrier
+// latencies with one wave per SIMD - about 1200 instructions (716 VALU, 19 MFMA) and 15 000 cycles
+// per wave and step, the MFMA pipe 8 % busy; halving the chains per block to double the blocks per
+// CU was measured and lost (10.9 vs 8.9 us per step at the time: the idle tile rows cost more than
+// the overlap wins).
 //
 // Reference semantics: MCMC.py:225-286 (sample), Proposal.py:127-164 (getNewParams),
 // binnedClModel.py:125-132 (prior), ClData_CosmoMC.py:267-315 (calcLnLike), MCMC.py:290-340
