@@ -38,7 +38,7 @@ struct GmhState {
   }
 };
 
-constexpr int kGraphSteps = 8;      // MH steps captured per graph (even: two counter slots)
+constexpr int kGraphSteps = 32;     // MH steps captured per graph (even: two counter slots)
 constexpr int64_t kGraphMinSteps = 32;
 
 void gmh_destroy(GmhState* g) { delete g; }
