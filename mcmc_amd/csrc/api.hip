@@ -223,7 +223,6 @@ struct LaunchRun {
     const int bs = pick_block(c->C, c->nbm, c->S, &lds);
     MI355_REQUIRE(bs > 0, "band tables (nb_max=%d, C=%d) do not fit in LDS", c->nbm, c->C);
     const unsigned grid = static_cast<unsigned>(ceil_div(c->N, bs));
-    if (c->kc.fast_ok != 0.0 && c->nslow > 0 && build_block_lists(c, bs)) return -2;
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
     if constexpr (M == MI355_SED_M2N || M == MI355_SED_M2N_LOGA) {
       const size_t lds_inc = lds + 2 * static_cast<size_t>(kIncBands) * bs * sizeof(double);
@@ -239,10 +238,32 @@ struct LaunchRun {
       // extended sampler: correlated / rotated proposals, co-moments (sed_mh_fused_ok checked it fits);
       // its own block size: the per-lane sqrt matrices count against LDS
       const SedPlan pe = sed_plan(c, true);
-      MI355_REQUIRE(sed_all_fast(c) && pe.bs > 0,
-                    "the extended fused sampler does not serve this catalogue (step-wise engine only)");
+      MI355_REQUIRE(pe.bs > 0, "the extended fused sampler does not serve this catalogue (step-wise engine only)");
       const unsigned grid_e = static_cast<unsigned>(ceil_div(c->N, pe.bs / pe.G));
-      if constexpr (M != MI355_SED_M2) {
+      if (!sed_all_fast(c)) {
+        // sources outside the fast domain (sed_plan keeps lane = chain then): the per-lane instantiation
+        // for the whole grid, or - mixed catalogue - for the blocks that hold such a source, beside the
+        // fast instantiation for all the others, as the plain sampler below
+        if (c->kc.fast_ok == 0.0) {
+          if (launch_lds((k_mh_run<M, false, true>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2;
+        } else {
+          if (build_block_lists(c, pe.bs)) return -2;
+          MhArgs af = a, as = a;
+          af.blocklist = c->blk_fast.p;
+          as.blocklist = c->blk_slow.p;
+          MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
+          MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+          if (launch_lds((k_mh_run<M, false, true>), static_cast<unsigned>(c->nblk_slow), pe.bs, pe.lds, c->stream2, as))
+            return -2;
+          MI355_HIP(hipGetLastError());
+          MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
+          if (c->nblk_fast > 0) {
+            if (launch_lds((k_mh_run<M, true, true>), static_cast<unsigned>(c->nblk_fast), pe.bs, pe.lds, c->stream, af))
+              return -2;
+          }
+          MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
+      } else if constexpr (M != MI355_SED_M2) {
         if (pe.G == 8)
           { if (launch_lds((k_mh_run<M, true, true, 8>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }
         else if (pe.G == 32)
@@ -270,6 +291,7 @@ struct LaunchRun {
     else {
       // mixed catalogue: the blocks with a source outside the fast domain on stream2 (each lane
       // follows its own source there), all the others through the fast instantiation beside them
+      if (build_block_lists(c, bs)) return -2;
       MhArgs af = a, as = a;
       af.blocklist = c->blk_fast.p;
       as.blocklist = c->blk_slow.p;
@@ -734,10 +756,10 @@ int mi355_mh_init(mi355_ctx* c, int32_t C, const double* theta0, int32_t theta0_
 
 namespace mi355 {
 // Whether chains started by mi355_mh_init_problem on the SED catalogue can run in the fused kernel
-// (its extended instantiation): clamp-free fast path, parameters within the block-mask tables,
-// LDS for the band tables plus the per-lane sqrt matrix.
+// (its extended instantiation): parameters within the block-mask tables, LDS for the band tables plus
+// the per-lane sqrt matrix.  (Sources outside the fast kernels' domain run in its per-lane instantiation.)
 bool sed_mh_fused_ok(const mi355_ctx* c) {
-  if (!c || !c->sed_loaded || !sed_all_fast(c) || c->P > kMaxParam) return false;
+  if (!c || !c->sed_loaded || c->P > kMaxParam) return false;
   return sed_plan(c, true).bs > 0;
 }
 }  // namespace mi355

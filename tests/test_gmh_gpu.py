@@ -340,17 +340,23 @@ def test_graph_replay_survives_scratch_regrowth(kind):
         assert np.array_equal(res[0][key], res[1][key]), key
 
 
-def test_sed_mixed_catalogue_stepwise_equals_fused():
-    """A catalogue with sources outside the fast kernels' domain: chains started by mi355_mh_init_problem
-    run on the launch-per-step engine there (the extended kernel wants an all-fast catalogue), each
-    source on its own path (k_sed_lnlike follows the per-source flag) - the same chains, bit for bit,
-    as the two side-by-side launches of the plain fused sampler (mi355_mh_init) on the same draws."""
-    from mcmc_amd import Engine, synth
-    S, C, P = 20, 16, 6
-    nu, d, sig, truth = synth.sed_catalogue(S, seed=12)
+def _mixed_catalogue(S=20, seed=12):
+    from mcmc_amd import synth
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=seed)
     nu = nu.copy()
     nu[[2, 17], 0] = 1.4                                   # radio points: sources 2 and 17 take the exact path
-    nb = np.full(S, 8, np.int32)
+    return nu, d, sig, truth, np.full(S, 8, np.int32)
+
+
+def test_sed_mixed_catalogue_stepwise_equals_fused():
+    """A catalogue with sources outside the fast kernels' domain, chains started by mi355_mh_init_problem:
+    the extended fused sampler runs the blocks that hold such a source in its per-lane instantiation
+    beside the fast one for the others, and the launch-per-step engine follows the per-source flag in
+    k_sed_lnlike - the same chains, bit for bit, as the two side-by-side launches of the plain fused
+    sampler (mi355_mh_init) on the same draws."""
+    from mcmc_amd import Engine
+    S, C, P = 20, 16, 6
+    nu, d, sig, truth, nb = _mixed_catalogue(S)
     start = truth[:, None, :].repeat(C, axis=1)
     sg = np.full(P, 0.02)
     with Engine(seed=31) as e:
@@ -360,17 +366,56 @@ def test_sed_mixed_catalogue_stepwise_equals_fused():
         e.mh_run(50, thin=1)
         ta = e.mh_trace()
         ma = e.mh_moments()
-    with Engine(seed=31) as e:
-        e.sed_load("M2N", nb, nu, d, sig)
-        e.mh_init_problem("sed", C, start, sg, param_blocks=np.arange(P), randomize_start=False)
-        assert not e.mh_fused_active
-        e.mh_run(50, thin=1)
-        tb = e.mh_trace()
-        mb = e.mh_moments()
+    for fused in (True, False):
+        with Engine(seed=31) as e:
+            e.sed_load("M2N", nb, nu, d, sig)
+            e.mh_init_problem("sed", C, start, sg, param_blocks=np.arange(P), randomize_start=False)
+            e.mh_set_fused(fused)
+            assert e.mh_fused_active == fused
+            e.mh_run(50, thin=1)
+            tb = e.mh_trace()
+            mb = e.mh_moments()
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x, y, equal_nan=True), fused
+        for k in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
+            assert np.array_equal(ma[k], mb[k], equal_nan=True), (k, fused)
+
+
+@pytest.mark.parametrize("kind", ["mixed", "none_fast"])
+def test_sed_extended_kernel_off_the_fast_domain(kind):
+    """Correlated proposals and co-moments on a catalogue that is partly ("mixed") or wholly
+    ("none_fast": a radio point in every source) outside the fast kernels' domain: the extended
+    fused sampler serves it (no drop to 30 us per step) and equals the launch-per-step engine."""
+    from mcmc_amd import Engine
+    S, C, P = 20, 16, 6
+    nu, d, sig, truth, nb = _mixed_catalogue(S)
+    if kind == "none_fast":
+        nu[:, 0] = 1.4
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T + P * np.eye(P)
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    start = truth[:, None, :].repeat(C, axis=1)
+    res = []
+    for fused in (True, False):
+        with Engine(seed=5) as e:
+            e.sed_load("M2N", nb, nu, d, sig)
+            assert e.sed_fast_sources == (S - 2 if kind == "mixed" else 0)
+            e.mh_init_problem("sed", C, start, np.full(P, 0.02), randomize_start=False, track_cov=True,
+                              param_blocks=np.arange(P) if kind == "mixed" else None)
+            e.mh_set_fused(fused)
+            assert e.mh_fused_active == fused
+            e.mh_set_sqrt_matrix(L, rotate=(kind == "mixed"))
+            e.mh_run(40, thin=2)
+            res.append((e.mh_trace(), e.mh_moments(), e.mh_covar(normalized=False)))
+    (ta, ma, ca), (tb, mb, cb) = res
     for x, y in zip(ta, tb):
         assert np.array_equal(x, y, equal_nan=True)
-    for k in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
+    for k in ma:
         assert np.array_equal(ma[k], mb[k], equal_nan=True), k
+    assert np.array_equal(ca, cb, equal_nan=True)
+    assert ma["naccept"].sum() > 0
 
 
 @pytest.mark.parametrize("lane_map", [1, 2])
