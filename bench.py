@@ -348,7 +348,7 @@ def main():
                      "note": "FP64 VALU (transcendental-bound); algorithmic FLOP = 1342 per MH step "
                              "(SURVEY 8d convention, 1 transcendental = 32 FLOP) x S*C*inner steps "
                              "per launch; traffic = HBM bytes per launch from rocprofv3 PMC "
-                             "(profiles/r1_bench_summary.txt), ~1% of the 8 TB/s roof"},
+                             "(profiles/r2_bench_summary.txt), ~1% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
         # fraction of sources whose worst parameter has R-hat < 1.1 (reference formula,
         # convergence.py:77-85) after adapt + warmup + timed steps
