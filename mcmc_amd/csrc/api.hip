@@ -216,6 +216,14 @@ static bool incremental_applies(const mi355_ctx* c) {
   return true;
 }
 
+// One parameter per block, block b = parameter b: the plain sampler then runs its in-place instantiation.
+static bool single_blocks(const mi355_ctx* c) {
+  if (c->nblock <= 0 || c->npn != 1) return false;
+  for (int b = 0; b < c->nblock; ++b)
+    if (c->blockmask[b] != (1u << b)) return false;
+  return true;
+}
+
 template <int M>
 struct LaunchRun {
   static int run(mi355_ctx* c, const MhArgs& a) {
@@ -281,6 +289,8 @@ struct LaunchRun {
           { if (launch_lds((k_mh_run<M, true, false, 8>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
         else if (pp.G == 32)
           { if (launch_lds((k_mh_run<M, true, false, 32>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
+        else if (single_blocks(c))
+          { if (launch_lds((k_mh_run<M, true, false, 1, true>), grid, bs, lds, c->stream, a)) return -2; }
         else
           { if (launch_lds((k_mh_run<M, true>), grid, bs, lds, c->stream, a)) return -2; }
       } else {

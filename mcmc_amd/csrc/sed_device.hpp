@@ -131,6 +131,33 @@ __device__ __forceinline__ bool all_finite(const double* th) {
   return s < __builtin_inf();
 }
 
+// package() as an involution: the exchange itself, and package() reporting whether it exchanged
+// (k_mh_run's in-place step undoes it on a rejected lane).
+template <int MODEL>
+__device__ __forceinline__ void sed_package_swap(double* th) {
+  if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+    double t;
+    t = th[0]; th[0] = th[3]; th[3] = t;
+    t = th[1]; th[1] = th[4]; th[4] = t;
+    t = th[2]; th[2] = th[5]; th[5] = t;
+  } else if constexpr (MODEL == MI355_SED_M2) {
+    double t;
+    t = th[0]; th[0] = th[2]; th[2] = t;
+    t = th[1]; th[1] = th[3]; th[3] = t;
+  }
+}
+template <int MODEL>
+__device__ __forceinline__ bool sed_package_flag(double* th) {
+  bool sw = false;
+  if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) sw = th[2] > th[5];
+  else if constexpr (MODEL == MI355_SED_M2) sw = th[1] > th[3];
+  if (__builtin_amdgcn_ballot_w64(sw) != 0) {             // rare: a wave-level branch instead of P selects
+    asm volatile("");
+    if (sw) sed_package_swap<MODEL>(th);
+  }
+  return sw;
+}
+
 // ---- likelihood, fast path -------------------------------------------------------------------
 // like.lnLike(theta) WITHOUT the prior, for theta INSIDE the prior box and finite (the only
 // points a Metropolis step can accept): T>=Tmin>0 so every Planck argument is positive, and the

@@ -262,9 +262,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // a wave (sed_plan in api.hip), for the plain and the extended sampler alike.  Same draws, same
 // arithmetic in the same order: the chains are identical bit for bit under either mapping
 // (tests/test_sed_gpu.py, tests/test_gmh_gpu.py).
-template <int MODEL, bool FAST, bool EXT = false, int G = 1>
+// SINGLE: one parameter per block with block b = parameter b (the production configuration,
+// driver.py:329-332; the launcher checks it) and no sqrt matrix.  The block index is launch-uniform,
+// so "which parameter moves" is a scalar branch: the step changes th[blk] in place, evaluates th, and
+// a rejected lane puts the one old value back - instead of a masked update of all P parameters into a
+// copy and a P-wide select at the accept.  Same arithmetic on the moved parameter (th + z sigma),
+// bit-identical chains (tests/test_sed_gpu.py compares the two instantiations).
+template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
+  static_assert(!SINGLE || (!EXT && G == 1), "single-parameter blocks: plain sampler, lane = chain");
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -336,13 +343,38 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   double za = 0.0, zb = 0.0, ua = 0.0, ub = 0.0;   // cached Philox pairs (npn == 1)
 
   for (int64_t t = 0; t < a.nsteps; ++t) {
-    const uint32_t mask = a.nblock ? a.blockmask[blk] : allmask;
+    const uint32_t mask = SINGLE ? 0u : (a.nblock ? a.blockmask[blk] : allmask);
     const uint64_t step = static_cast<uint64_t>(a.step_total + t);
-    double nw[P];
+    double nwc[SINGLE ? 1 : P];                            // the proposed point (a copy) ...
+    double* const nw = SINGLE ? th : nwc;                  // ... or the state itself, moved in place
+    double old = 0.0;                                      // SINGLE: th[blk] before the step
+    bool swapped = false;                                  // SINGLE: package() exchanged the components
+    if constexpr (!SINGLE) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) nw[i] = th[i];
+      for (int i = 0; i < P; ++i) nwc[i] = th[i];
+    }
     double u;
-    if (EXT && a.mode != 0) {
+    if constexpr (SINGLE) {
+      double z;
+      if (inject) {
+        z = a.inj_n[(t * a.N + n) * P + blk];
+        u = a.inj_u[t * a.N + n];
+      } else {
+        if (t == 0 || (step & 1u) == 0) {
+          philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+          philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
+        }
+        z = (step & 1u) ? zb : za;
+        u = (step & 1u) ? ub : ua;
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        if (blk == i) {                                    // scalar branch: blk is launch-uniform
+          asm volatile("");                                // (keeps the optimizer from flattening it into P selects)
+          old = th[i];
+          th[i] = old + z * sg[i];                         // Proposal.py:151,156-159
+        }
+    } else if (EXT && a.mode != 0) {
       // z_j of the step: correlated - normal(step npn + j) for every j; rotated - normal(step npn +
       // rank_j) for the members j of the block (injected rows: element j / element rank_j)
       double z[P];
@@ -407,7 +439,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
         u = philox_uniform(a.seed, RNG_UNIFORM, n, step);
       }
     }
-    sed_package<MODEL>(nw);                                // Proposal.py:164
+    if constexpr (SINGLE) swapped = sed_package_flag<MODEL>(nw);
+    else sed_package<MODEL>(nw);                           // Proposal.py:164
     // The reference evaluates the likelihood before the prior (MCMC.py:236-245); the outcome
     // (reject, keep prev) is the same with the prior tested first, which skips the evaluation.
     const double prior = sed_prior<MODEL>(nw, a.k);
@@ -436,7 +469,23 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
         }
       }
     }
-    if (accepted) {
+    if constexpr (SINGLE) {
+      if (accepted) {
+        lnPr = next;
+        ++nacc;                                            // :269
+      }
+      if (__builtin_amdgcn_ballot_w64(swapped && !accepted) != 0) {   // rare: a wave-level branch
+        asm volatile("");
+        if (swapped && !accepted) sed_package_swap<MODEL>(th);        // back to the order the old value belongs to
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        if (blk == i) {
+          asm volatile("");
+          th[i] = accepted ? th[i] : old;
+          accb[i] += accepted ? 1u : 0u;                   // :271
+        }
+    } else if (accepted) {
 #pragma unroll
       for (int i = 0; i < P; ++i) th[i] = nw[i];
       lnPr = next;
