@@ -133,6 +133,16 @@ __device__ __forceinline__ double exp2_fast(double y) {
   return ldexp(fma(exp2m1_over_f(f), f, 1.0), static_cast<int>(fn));
 }
 
+// p z + c as ONE v_fma_f64 with the polynomial constant c in a register pair.  Written out because the
+// compiler's own lowering of a Horner step whose constant it keeps in VGPRs across the MH loop is
+// v_mov_b64 (a copy of the constant) + v_fmac_f64: two issue slots where one does (20 such copies per
+// Box-Muller pair, one per band in the band loop).  Same operation, same bits.
+__device__ __forceinline__ double fma_k(double p, double z, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "v"(c));
+  return r;
+}
+
 // ---- table-driven 2^y (the band loop of the SED fast path) ------------------------------------
 // y = k/2048 + f with k = round(2048 y) taken from the low mantissa bits of y + 1.5 2^41 (no
 // v_rndne / v_cvt), |f| <= 2^-12:  2^y = 2^(k >> 11) * T[k & 2047] * (1 + f P(f)),  T[i] = 2^(i/2048)
@@ -260,16 +270,16 @@ __device__ __forceinline__ double log_fast(double u) {
   const double s = div_fast(f, 2.0 + f);
   const double z = s * s;
   double r = 2.0 / 23.0;
-  r = fma(r, z, 2.0 / 21.0);
-  r = fma(r, z, 2.0 / 19.0);
-  r = fma(r, z, 2.0 / 17.0);
-  r = fma(r, z, 2.0 / 15.0);
-  r = fma(r, z, 2.0 / 13.0);
-  r = fma(r, z, 2.0 / 11.0);
-  r = fma(r, z, 2.0 / 9.0);
-  r = fma(r, z, 2.0 / 7.0);
-  r = fma(r, z, 2.0 / 5.0);
-  r = fma(r, z, 2.0 / 3.0);
+  r = fma_k(r, z, 2.0 / 21.0);
+  r = fma_k(r, z, 2.0 / 19.0);
+  r = fma_k(r, z, 2.0 / 17.0);
+  r = fma_k(r, z, 2.0 / 15.0);
+  r = fma_k(r, z, 2.0 / 13.0);
+  r = fma_k(r, z, 2.0 / 11.0);
+  r = fma_k(r, z, 2.0 / 9.0);
+  r = fma_k(r, z, 2.0 / 7.0);
+  r = fma_k(r, z, 2.0 / 5.0);
+  r = fma_k(r, z, 2.0 / 3.0);
   const double lm = fma(s * z, r, s + s);
   const double fe = static_cast<double>(e);
   return fma(fe, kLn2Hi, fma(fe, kLn2Lo, lm));
@@ -295,18 +305,18 @@ __device__ __forceinline__ void sincos2pi_fast(double u, double* sn, double* cs)
   const double y = fma(f, 0x1.1a62633145c07p-54, f * 0x1.921fb54442d18p+0);   // f * pi/2
   const double z = y * y;
   double rs = 1.58969099521155010221e-10;
-  rs = fma(rs, z, -2.50507602534068634195e-08);
-  rs = fma(rs, z, 2.75573137070700676789e-06);
-  rs = fma(rs, z, -1.98412698298579493134e-04);
-  rs = fma(rs, z, 8.33333333332248946124e-03);
-  rs = fma(rs, z, -1.66666666666666324348e-01);
+  rs = fma_k(rs, z, -2.50507602534068634195e-08);
+  rs = fma_k(rs, z, 2.75573137070700676789e-06);
+  rs = fma_k(rs, z, -1.98412698298579493134e-04);
+  rs = fma_k(rs, z, 8.33333333332248946124e-03);
+  rs = fma_k(rs, z, -1.66666666666666324348e-01);
   const double s0 = fma(y * z, rs, y);
   double rc = -1.13596475577881948265e-11;
-  rc = fma(rc, z, 2.08757232129817482790e-09);
-  rc = fma(rc, z, -2.75573143513906633035e-07);
-  rc = fma(rc, z, 2.48015872894767294178e-05);
-  rc = fma(rc, z, -1.38888888888741095749e-03);
-  rc = fma(rc, z, 4.16666666666666019037e-02);
+  rc = fma_k(rc, z, 2.08757232129817482790e-09);
+  rc = fma_k(rc, z, -2.75573143513906633035e-07);
+  rc = fma_k(rc, z, 2.48015872894767294178e-05);
+  rc = fma_k(rc, z, -1.38888888888741095749e-03);
+  rc = fma_k(rc, z, 4.16666666666666019037e-02);
   const double c0 = fma(z * z, rc, fma(-0.5, z, 1.0));
   // angle = y + q pi/2
   const double sa = (q & 1) ? c0 : s0;

@@ -341,6 +341,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   int thin_ctr = 0;
   int64_t row = 0;
   double za = 0.0, zb = 0.0, ua = 0.0, ub = 0.0;   // cached Philox pairs (npn == 1)
+  double nsamp = static_cast<double>(a.nsamp0);    // samples in the moments so far (a 64-bit integer costs
+                                                   // four instructions per step to convert)
 
   for (int64_t t = 0; t < a.nsteps; ++t) {
     const uint32_t mask = SINGLE ? 0u : (a.nblock ? a.blockmask[blk] : allmask);
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 
     // running ddof=0 moments over every appended sample (mean/stdev with burn=1, :290-307)
 #if MI355_ABL != 1
-    const double rn = rcp_nr(static_cast<double>(a.nsamp0 + t + 1));   // 1/n to 2^-50
+    nsamp += 1.0;                                          // exact: a count below 2^53
+    const double rn = rcp_nr(nsamp);                       // 1/n to 2^-50
     double dl[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
