@@ -167,7 +167,7 @@ static SedPlan sed_plan(const mi355_ctx* c, bool ext) {
   if (g == 0 || c->nb_most < 2) return p;
   if (c->lane_map != 2 && c->N * g > 65536) return p;
   size_t lds = 0;
-  const int bs = pick_block_x(c, per_lane + sizeof(double2), 16, &lds);   // + the exchange slots
+  const int bs = pick_block_x(c, per_lane + 3 * sizeof(double2), 16, &lds);   // + the exchange slot, two slots of draws
   if (bs > 0) {
     p.bs = bs;
     p.lds = lds;

@@ -325,6 +325,40 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   double2* cb_slot = reinterpret_cast<double2*>(
                          smem + ((static_cast<size_t>(nsrc) * stride + (EXT ? static_cast<size_t>(NTRI) * blockDim.x : 0) + 1) &
                                  ~static_cast<size_t>(1))) + threadIdx.x;
+  // G > 1: the G lanes of a chain draw ahead.  The streams are counter-based, so lane jb computes pair
+  // number base + jb of the normal (uniform) stream, parks it in its 16-byte slot behind the exchange
+  // slots, and the chain reads the next G pairs with one broadcast each - Philox and Box-Muller, a
+  // third of a step's dependent instructions when every lane repeats them, run once per G pairs.
+  // Draws are consumed in stream order and the index is wave-uniform, so a refill is a scalar branch;
+  // the group is part of one wave, whose LDS operations execute in order (fences as in cb_publish).
+  double2* const nrm_slot = cb_slot + blockDim.x;          // (za, zb) of the lane's pair
+  double2* const uni_slot = nrm_slot + blockDim.x;         // (ua, ub)
+  uint64_t nrm_base = 0, uni_base = 0;
+  bool nrm_have = false, uni_have = false;
+  auto normal_at = [&](uint64_t idx) -> double {
+    const uint64_t pr = idx >> 1;
+    if (!nrm_have || pr - nrm_base >= static_cast<uint64_t>(G)) {
+      nrm_have = true;
+      nrm_base = pr;
+      double pa, pb;
+      philox_normal2(a.seed, RNG_NORMAL, n, pr + jb, pa, pb);
+      cb_publish(nrm_slot, pa, pb);
+    }
+    const double2 v = (nrm_slot - jb)[pr - nrm_base];
+    return (idx & 1u) ? v.y : v.x;
+  };
+  auto uniform_at = [&](uint64_t idx) -> double {
+    const uint64_t pr = idx >> 1;
+    if (!uni_have || pr - uni_base >= static_cast<uint64_t>(G)) {
+      uni_have = true;
+      uni_base = pr;
+      double qa, qb;
+      philox_uniform2(a.seed, RNG_UNIFORM, n, pr + jb, qa, qb);
+      cb_publish(uni_slot, qa, qb);
+    }
+    const double2 v = (uni_slot - jb)[pr - uni_base];
+    return (idx & 1u) ? v.y : v.x;
+  };
   if constexpr (EXT) {
     if (a.mode != 0) {
 #pragma unroll
@@ -390,17 +424,23 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 #pragma unroll
           for (int j = 0; j < P; j += 2) {
             double p0, p1;
-            philox_normal2(a.seed, RNG_NORMAL, n, (step * a.npn + j) >> 1, p0, p1);
+            if constexpr (G > 1) {
+              p0 = normal_at(step * a.npn + j);
+              p1 = normal_at(step * a.npn + j + 1);
+            } else {
+              philox_normal2(a.seed, RNG_NORMAL, n, (step * a.npn + j) >> 1, p0, p1);
+            }
             z[j] = p0;
             if (j + 1 < P) z[j + 1] = p1;
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < P; ++j)
-            z[j] = ((mask >> j) & 1u) ? philox_normal(a.seed, RNG_NORMAL, n, step * a.npn + a.rank_in_block[j])
-                                      : 0.0;
+          for (int j = 0; j < P; ++j) {
+            const uint64_t idx = step * a.npn + a.rank_in_block[j];
+            z[j] = ((mask >> j) & 1u) ? (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx)) : 0.0;
+          }
         }
-        u = philox_uniform(a.seed, RNG_UNIFORM, n, step);
+        u = G > 1 ? uniform_at(step) : philox_uniform(a.seed, RNG_UNIFORM, n, step);
       }
 #pragma unroll
       for (int i = 0; i < P; ++i) {
@@ -420,25 +460,33 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       u = a.inj_u[t * a.N + n];
     } else {
       if (a.npn == 1) {
+        double z;
+        if constexpr (G > 1) {
+          z = normal_at(step);
+          u = uniform_at(step);
+        } else {
 #if MI355_ABL == 2
-        za = 0.3; zb = -0.2; ua = 0.4; ub = 0.6;
+          za = 0.3; zb = -0.2; ua = 0.4; ub = 0.6;
 #else
-        if (t == 0 || (step & 1u) == 0) {
-          philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
-          philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
-        }
+          if (t == 0 || (step & 1u) == 0) {
+            philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+            philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
+          }
 #endif
-        const double z = (step & 1u) ? zb : za;
+          z = (step & 1u) ? zb : za;
+          u = (step & 1u) ? ub : ua;
+        }
 #pragma unroll
         for (int i = 0; i < P; ++i)
           if ((mask >> i) & 1u) nw[i] += z * sg[i];
-        u = (step & 1u) ? ub : ua;
       } else {
 #pragma unroll
         for (int i = 0; i < P; ++i)
-          if ((mask >> i) & 1u)
-            nw[i] += philox_normal(a.seed, RNG_NORMAL, n, step * a.npn + a.rank_in_block[i]) * sg[i];
-        u = philox_uniform(a.seed, RNG_UNIFORM, n, step);
+          if ((mask >> i) & 1u) {
+            const uint64_t idx = step * a.npn + a.rank_in_block[i];
+            nw[i] += (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx)) * sg[i];
+          }
+        u = G > 1 ? uniform_at(step) : philox_uniform(a.seed, RNG_UNIFORM, n, step);
       }
     }
     if constexpr (SINGLE) swapped = sed_package_flag<MODEL>(nw);
