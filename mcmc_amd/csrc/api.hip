@@ -285,7 +285,11 @@ struct LaunchRun {
       const SedPlan pp = sed_plan(c, false);
       const unsigned grid_g = static_cast<unsigned>(ceil_div(c->N, pp.bs / pp.G));
       if constexpr (M != MI355_SED_M2) {
-        if (pp.G == 8)
+        if (pp.G == 8 && single_blocks(c))
+          { if (launch_lds((k_mh_run<M, true, false, 8, true>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
+        else if (pp.G == 32 && single_blocks(c))
+          { if (launch_lds((k_mh_run<M, true, false, 32, true>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
+        else if (pp.G == 8)
           { if (launch_lds((k_mh_run<M, true, false, 8>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }
         else if (pp.G == 32)
           { if (launch_lds((k_mh_run<M, true, false, 32>), grid_g, pp.bs, pp.lds, c->stream, a)) return -2; }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
-  static_assert(!SINGLE || (!EXT && G == 1), "single-parameter blocks: plain sampler, lane = chain");
+  static_assert(!SINGLE || !EXT, "single-parameter blocks: plain sampler");
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -395,6 +395,9 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       if (inject) {
         z = a.inj_n[(t * a.N + n) * P + blk];
         u = a.inj_u[t * a.N + n];
+      } else if constexpr (G > 1) {
+        z = normal_at(step);
+        u = uniform_at(step);
       } else {
         if (t == 0 || (step & 1u) == 0) {
           philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
