@@ -314,8 +314,12 @@ struct LaunchRun {
       { if (launch_lds((k_mh_run<M, false>), static_cast<unsigned>(c->nblk_slow), bs, lds, c->stream2, as)) return -2; }
       MI355_HIP(hipGetLastError());
       MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
-      if (c->nblk_fast > 0)
-        { if (launch_lds((k_mh_run<M, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
+      if (c->nblk_fast > 0) {
+        if (single_blocks(c))
+          { if (launch_lds((k_mh_run<M, true, false, 1, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
+        else
+          { if (launch_lds((k_mh_run<M, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
+      }
       MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     MI355_HIP(hipGetLastError());
