@@ -381,6 +381,46 @@ def test_sed_mixed_catalogue_stepwise_equals_fused():
             assert np.array_equal(ma[k], mb[k], equal_nan=True), (k, fused)
 
 
+@pytest.mark.parametrize("model,lane_map", [("M2N", 1), ("M2N", 2), ("M2N_LOGA", 1), ("M1N", 1), ("THICK", 2)])
+def test_sed_in_place_instantiation_equals_stepwise_engine(model, lane_map):
+    """Single-parameter blocks through mi355_mh_init run the in-place instantiation of the fused sampler
+    (the moved parameter changed in th itself behind a scalar branch, package()'s exchange undone on a
+    rejected lane): the same chains, bit for bit, as the launch-per-step engine on the same draws - with
+    stage-0 widths, so that T1 > T2 exchanges and rejections of exchanged proposals both occur."""
+    from mcmc_amd import Engine, synth
+    S, C = 6, 24
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=8)
+    nb = np.array([8, 8, 7, 8, 5, 8], np.int32)
+    P = {"M2N": 6, "M2N_LOGA": 6, "M1N": 3, "THICK": 4}[model]
+    start = {"M2N": synth.M2N_START, "M2N_LOGA": [0.0, 2.0, 10.0, -1.0, 2.0, 20.0], "M1N": [1.0, 2.0, 10.0],
+             "THICK": [1.0, 2.0, 10.0, 1.0]}[model]
+    sg = {"M2N": synth.M2N_PROP_SIGMAS, "M2N_LOGA": [1.0, 4.0, 4.0, 1.0, 4.0, 4.0], "M1N": [2.0, 4.0, 4.0],
+          "THICK": [2.0, 4.0, 4.0, 0.5]}[model]
+    out = []
+    for stepwise in (False, True):
+        with Engine(seed=19) as e:
+            e.mh_set_lane_map(lane_map)
+            e.sed_load(model, nb, nu, d, sig)
+            if stepwise:
+                e.mh_init_problem("sed", C, np.array(start), np.array(sg), param_blocks=np.arange(P),
+                                  randomize_start=False)
+                e.mh_set_fused(False)
+                assert not e.mh_fused_active
+            else:
+                e.mh_init(C, np.array(start), np.array(sg), param_blocks=np.arange(P), randomize_start=False)
+            e.mh_run(300, thin=1)
+            e.mh_run(33, thin=1)                           # a second launch: odd stream position, block phase
+            out.append((e.mh_trace(), e.mh_moments()))
+    (ta, ma), (tb, mb) = out
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y, equal_nan=True)
+    for k in ("theta", "lnPr", "mean", "var", "naccept", "accept"):
+        assert np.array_equal(ma[k], mb[k], equal_nan=True), k
+    if P == 6:                                             # exchanges happened: the kept T1 <= T2 and moves were made
+        th = ta[0]
+        assert np.all(th[..., 2] <= th[..., 5]) and ma["naccept"].sum() > 0
+
+
 @pytest.mark.parametrize("kind", ["mixed", "none_fast"])
 def test_sed_extended_kernel_off_the_fast_domain(kind):
     """Correlated proposals and co-moments on a catalogue that is partly ("mixed") or wholly
