@@ -31,7 +31,7 @@ static __device__ __align__(256) double scratch[3 * MI355_RHAT_NOALLOC_MAX];
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr size_t kLdsBig = 128 * 1024;   // dynamic LDS of a block whose kernel has been opted in (launch_lds); 160 KB per CU
-constexpr size_t kLdsLimit = 64 * 1024 - kExp2Entries * sizeof(double);   // dynamic LDS a block may ask for without opt-in (static: the 16 KB 2^y table)
+constexpr size_t kLdsLimit = 64 * 1024 - kStaticTabBytes;   // dynamic LDS a block may ask for without opt-in (static: the 18 KB of 2^y and Box-Muller tables)
 
 // LDS bytes a `bs`-chain block needs for the band tables of the sources it can touch
 static size_t lds_bytes(int bs, int C, int nbm, int64_t nsources) {
@@ -1025,7 +1025,7 @@ int mi355_gauss_quadform(mi355_ctx* c, int64_t m, int64_t n, const double* A, co
 int mi355_math_probe(mi355_ctx* c, int32_t fn, int64_t n, const double* a, const double* b,
                      const double* cc, double* out) {
   MI355_REQUIRE(c && a && out && n > 0, "mi355_math_probe: bad argument");
-  MI355_REQUIRE(fn >= 0 && fn <= 12, "mi355_math_probe: unknown function %d", fn);
+  MI355_REQUIRE(fn >= 0 && fn <= 15, "mi355_math_probe: unknown function %d", fn);
   MI355_REQUIRE((fn != 2 && fn != 3) || b, "mi355_math_probe: b required");
   MI355_REQUIRE(fn != 2 || cc, "mi355_math_probe: c required");
   MI355_HIP(hipSetDevice(c->device));

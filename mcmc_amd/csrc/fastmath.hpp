@@ -159,13 +159,25 @@ static __device__ const double kExp2Table[kExp2Entries] = {
 #include "exp2_table.inc"
 };
 
-// The block's copy of the table in LDS.  Every thread of the block must call this before the
-// block's next __syncthreads(); the pointer is valid after that barrier.
+// The 64-row table of the Box-Muller kernels below (log_bm, sincos_bm; tools/gen_bm_table.py):
+// row k = (1/c_k, ln c_k, sin(2 pi k/64), cos(2 pi k/64)).
+constexpr int kBmEntries = 64;
+static __device__ const double kBmTable[4 * kBmEntries] = {
+#include "bm_table.inc"
+};
+// Static LDS of every kernel that stages the tables (18 KB): host code sizes dynamic LDS against it.
+constexpr size_t kStaticTabBytes = (kExp2Entries + 4 * kBmEntries) * sizeof(double);
+
+// The block's copy of the tables in LDS: 2^(i/2048), then the Box-Muller rows (bm_of()).  Every
+// thread of the block must call this before the block's next __syncthreads(); the pointer is valid
+// after that barrier.
 __device__ __forceinline__ const double* stage_exp2_table() {
-  __shared__ double tab[kExp2Entries];
+  __shared__ __align__(16) double tab[kExp2Entries + 4 * kBmEntries];
   for (int i = threadIdx.x; i < kExp2Entries; i += blockDim.x) tab[i] = kExp2Table[i];
+  for (int i = threadIdx.x; i < 4 * kBmEntries; i += blockDim.x) tab[kExp2Entries + i] = kBmTable[i];
   return tab;
 }
+__device__ __forceinline__ const double* bm_of(const double* e2t) { return e2t + kExp2Entries; }
 
 // N independent 2^y[i] at once (|y| < 1000, tab = stage_exp2_table()), written stage by stage
 // (reductions and table reads of all N first, then the Horner steps of the N chains interleaved)
@@ -323,6 +335,54 @@ __device__ __forceinline__ void sincos2pi_fast(double u, double* sn, double* cs)
   const double ca = (q & 1) ? s0 : c0;
   *sn = (q & 2) ? -sa : sa;
   *cs = ((q + 1) & 2) ? -ca : ca;
+}
+
+// ---- Box-Muller kernels, table-driven -----------------------------------------------------------
+// ln(u), u in (0, 1) and normal (the 53-bit uniforms of philox.hpp): u = m 2^e, m in [1/2, 1); the top
+// six mantissa bits of m pick c_k; r = m/c_k - 1 is one FMA (1/c_k has 9 bits: the product is rounded
+// once, relative error 2^-53), |r| <= 0.0084; ln u = e ln 2 + ln c_k + log1p(r), log1p by its series
+// through r^8.  Row 63 is c = 1: the logarithm of u -> 1 keeps its relative accuracy (the only place
+// where the sum is small).  18 instructions against the 36 of log_fast (no division), <= 1 ulp
+// (tests/test_fastmath_gpu.py).  bm = bm_of(stage_exp2_table()) or kBmTable itself.
+__device__ __forceinline__ double log_bm(double u, const double* bm) {
+  const int e = __builtin_amdgcn_frexp_exp(u);
+  const double m = __builtin_amdgcn_frexp_mant(u);         // [0.5, 1)
+  const unsigned off = (static_cast<unsigned>(__double2hiint(m)) >> 9) & 0x7e0u;   // 32-byte rows
+  const double2 t = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(bm) + off);
+  const double r = fma(m, t.x, -1.0);
+  double p = -1.0 / 8.0;
+  p = fma(p, r, 1.0 / 7.0);
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 1.0 / 5.0);
+  p = fma(p, r, -1.0 / 4.0);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -1.0 / 2.0);
+  const double l = fma(r * r, p, r);
+  const double fe = static_cast<double>(e);
+  return fma(fe, kLn2Hi, fma(fe, kLn2Lo, t.y + l));
+}
+
+// sin(2 pi u), cos(2 pi u), u in [0, 1): u = k/64 + f/64 with k = round(64 u) read off the low mantissa
+// bits of 64 u + 1.5 2^52 and |f| <= 1/2 exact; the rotation of (sin, cos)(2 pi k/64) from the table
+// by b = f pi/32, |b| <= 0.05 (sine through b^7, cosine - 1 through b^8).  21 instructions against 46
+// (no quadrant selects); absolute error <= 2e-16 - a value near zero is NOT relatively accurate, which
+// the product with Box-Muller's radius does not need.
+__device__ __forceinline__ void sincos_bm(double u, const double* bm, double* sn, double* cs) {
+  const double a = 64.0 * u;
+  const double t = a + 0x1.8p52;
+  const double f = a - (t - 0x1.8p52);                     // exact
+  const unsigned off = (static_cast<unsigned>(__double2loint(t)) << 5) & 0x7e0u;
+  const double2 sc = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(bm) + off + 16);
+  const double b = fma(f, 0x1.1a62633145c07p-58, f * 0x1.921fb54442d18p-4);   // f * pi/32
+  const double z = b * b;
+  double ps = fma(-1.0 / 5040.0, z, 1.0 / 120.0);
+  ps = fma(ps, z, -1.0 / 6.0);
+  const double sb = fma(b * z, ps, b);                     // sin b
+  double pc = fma(1.0 / 40320.0, z, -1.0 / 720.0);
+  pc = fma(pc, z, 1.0 / 24.0);
+  const double cm1 = fma(z * z, pc, -0.5 * z);             // cos b - 1
+  *sn = fma(sc.y, sb, fma(sc.x, cm1, sc.x));
+  *cs = fma(-sc.x, sb, fma(sc.y, cm1, sc.y));
 }
 
 }  // namespace mi355

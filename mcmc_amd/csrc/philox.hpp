@@ -6,9 +6,9 @@
 //   words w0..w3 -> u1 = u53(w0,w1), u2 = u53(w2,w3),  u53(hi,lo) = ((hi<<21 | lo>>11)+0.5)*2^-53
 //   uniform(idx)  = idx even ? u1 : u2
 //   normal(idx)   = sqrt(-2 ln u1) * (idx even ? cos : sin)(2 pi u2)
-// ln and sin/cos are the library's own short kernels (fastmath.hpp: a few ulp, no large-argument
-// paths); the oracle evaluates the same formula with numpy, so device and oracle normals agree
-// to ~1e-15 relative, far inside the 1e-12 chain tolerances.
+// ln and sin/cos are the library's own table-driven kernels (fastmath.hpp log_bm, sincos_bm: ln to
+// 1 ulp, sine and cosine to 2e-16 absolute); the oracle evaluates the same formula with numpy, so
+// device and oracle normals agree to ~1e-15 absolute, far inside the 1e-12 chain tolerances.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -69,22 +69,28 @@ __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t purpose,
   ub = u53(r.w[2], r.w[3]);
 }
 
-// both normals of one pair (cos branch = even idx, sin branch = odd idx)
+// both normals of one pair (cos branch = even idx, sin branch = odd idx); bm: the Box-Muller table,
+// bm_of(stage_exp2_table()) in the kernels that stage it, the table in device memory otherwise
+// (same rows, same arithmetic, same normals)
 __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t purpose, uint64_t chain,
-                                               uint64_t pair, double& za, double& zb) {
+                                               uint64_t pair, const double* bm, double& za, double& zb) {
   double u1, u2;
   philox_uniform2(seed, purpose, chain, pair, u1, u2);
-  const double r = sqrt_fast(-2.0 * log_fast(u1));
+  const double r = sqrt_fast(-2.0 * log_bm(u1, bm));
   double s, c;
-  sincos2pi_fast(u2, &s, &c);
+  sincos_bm(u2, bm, &s, &c);
   za = r * c;
   zb = r * s;
 }
+__device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t purpose, uint64_t chain,
+                                               uint64_t pair, double& za, double& zb) {
+  philox_normal2(seed, purpose, chain, pair, kBmTable, za, zb);
+}
 
 __device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t purpose, uint64_t chain,
-                                                uint64_t idx) {
+                                                uint64_t idx, const double* bm = kBmTable) {
   double za, zb;
-  philox_normal2(seed, purpose, chain, idx >> 1, za, zb);
+  philox_normal2(seed, purpose, chain, idx >> 1, bm, za, zb);
   return (idx & 1) ? zb : za;
 }
 

@@ -210,7 +210,23 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double ae1 = A1 * (eb[0] - 1.0);
     const double ae2 = A2 * (eb[1] - 1.0);
     double chi2 = 0.0;
-    for (int j = 0; j < B.nbu; ++j) {
+    int j = 0;
+    // two bands at a time (their eight exponentials interleaved), terms added in band order
+    for (; j + 1 < B.nbu; j += 2) {
+      const double hna = B.hnu2(j), lha = B.lhi(j), hnb = B.hnu2(j + 1), lhb = B.lhi(j + 1);
+      const double y1a = hna * rT1, y2a = hna * rT2, y1b = hnb * rT1, y2b = hnb * rT2;
+      const double z[8] = {fma(e1, lha, -y1a), -y1a, fma(e2, lha, -y2a), -y2a,
+                           fma(e1, lhb, -y1b), -y1b, fma(e2, lhb, -y2b), -y2b};
+      double pw[8];
+      exp2_tab_n<8>(z, B.e2t, pw);
+      const double n1a = pw[0] * ae1, d1a = 1.0 - pw[1], n2a = pw[2] * ae2, d2a = 1.0 - pw[3];
+      const double n1b = pw[4] * ae1, d1b = 1.0 - pw[5], n2b = pw[6] * ae2, d2b = 1.0 - pw[7];
+      const double ra = B.d(j) - div_fast(fma(n1a, d2a, n2a * d1a), d1a * d2a);
+      const double rb = B.d(j + 1) - div_fast(fma(n1b, d2b, n2b * d1b), d1b * d2b);
+      chi2 = fma(ra * B.w(j), ra, chi2);
+      chi2 = fma(rb * B.w(j + 1), rb, chi2);
+    }
+    for (; j < B.nbu; ++j) {
       const double hn = B.hnu2(j), lh = B.lhi(j);
       const double y1 = hn * rT1, y2 = hn * rT2;
       const double z[4] = {fma(e1, lh, -y1), -y1, fma(e2, lh, -y2), -y2};

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
   const double* e2t = stage_exp2_table();
+  const double* bmt = bm_of(e2t);                        // Box-Muller rows of the same LDS table
   stage_bands(smem, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 #pragma unroll
       for (int i = 0; i < P; i += 2) {
         double za, zb;
-        philox_normal2(a.seed, RNG_START, n, (sbase + i) >> 1, za, zb);
+        philox_normal2(a.seed, RNG_START, n, (sbase + i) >> 1, bmt, za, zb);
         c[i] += za * sd[i];
         if (i + 1 < P) c[i + 1] += zb * sd[i + 1];
       }
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 #pragma unroll
       for (int i = 0; i < P; i += 2) {
         double za, zb;
-        philox_normal2(a.seed, RNG_START, n, (base + i) >> 1, za, zb);
+        philox_normal2(a.seed, RNG_START, n, (base + i) >> 1, bmt, za, zb);
         th[i] = c[i] + za * sg[i];
         if (i + 1 < P) th[i + 1] = c[i + 1] + zb * sg[i + 1];
       }
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
   const double* e2t = stage_exp2_table();
+  const double* bmt = bm_of(e2t);                        // Box-Muller rows of the same LDS table
   stage_bands(smem, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x / G;
   const int jb = threadIdx.x % G;                          // the lane's band (G > 1)
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       nrm_have = true;
       nrm_base = pr;
       double pa, pb;
-      philox_normal2(a.seed, RNG_NORMAL, n, pr + jb, pa, pb);
+      philox_normal2(a.seed, RNG_NORMAL, n, pr + jb, bmt, pa, pb);
       cb_publish(nrm_slot, pa, pb);
     }
     const double2 v = (nrm_slot - jb)[pr - nrm_base];
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
         u = uniform_at(step);
       } else {
         if (t == 0 || (step & 1u) == 0) {
-          philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+          philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, bmt, za, zb);
           philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
         }
         z = (step & 1u) ? zb : za;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
               p0 = normal_at(step * a.npn + j);
               p1 = normal_at(step * a.npn + j + 1);
             } else {
-              philox_normal2(a.seed, RNG_NORMAL, n, (step * a.npn + j) >> 1, p0, p1);
+              philox_normal2(a.seed, RNG_NORMAL, n, (step * a.npn + j) >> 1, bmt, p0, p1);
             }
             z[j] = p0;
             if (j + 1 < P) z[j + 1] = p1;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             const uint64_t idx = step * a.npn + a.rank_in_block[j];
-            z[j] = ((mask >> j) & 1u) ? (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx)) : 0.0;
+            z[j] = ((mask >> j) & 1u) ? (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx, bmt)) : 0.0;
           }
         }
         u = G > 1 ? uniform_at(step) : philox_uniform(a.seed, RNG_UNIFORM, n, step);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
           za = 0.3; zb = -0.2; ua = 0.4; ub = 0.6;
 #else
           if (t == 0 || (step & 1u) == 0) {
-            philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+            philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, bmt, za, zb);
             philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
           }
 #endif
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
         for (int i = 0; i < P; ++i)
           if ((mask >> i) & 1u) {
             const uint64_t idx = step * a.npn + a.rank_in_block[i];
-            nw[i] += (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx)) * sg[i];
+            nw[i] += (G > 1 ? normal_at(idx) : philox_normal(a.seed, RNG_NORMAL, n, idx, bmt)) * sg[i];
           }
         u = G > 1 ? uniform_at(step) : philox_uniform(a.seed, RNG_UNIFORM, n, step);
       }
@@ -638,6 +640,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;
   const double* e2t = stage_exp2_table();
+  const double* bmt = bm_of(e2t);                        // Box-Muller rows of the same LDS table
   stage_bands(tables, a.bands, s_first, nsrc, stride);
   const int64_t n = n0 + threadIdx.x;
   if (n >= a.N) return;
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
       u = a.inj_u[t * a.N + n];
     } else {
       if (t == 0 || (step & 1u) == 0) {
-        philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, za, zb);
+        philox_normal2(a.seed, RNG_NORMAL, n, step >> 1, bmt, za, zb);
         philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
       }
       z = (step & 1u) ? zb : za;
@@ -810,6 +813,9 @@ __global__ void k_math_probe(int fn, int64_t n, const double* a, const double* b
     case 10: v = exp2_fast(a[i]); break;
     case 11: v = sqrt_fast(a[i]); break;
     case 12: v = u53(static_cast<uint32_t>(a[i]), static_cast<uint32_t>(b[i])); break;
+    case 13: v = log_bm(a[i], bm_of(tab)); break;
+    case 14: { double sn, cs; sincos_bm(a[i], bm_of(tab), &sn, &cs); v = sn; break; }
+    case 15: { double sn, cs; sincos_bm(a[i], kBmTable, &sn, &cs); v = cs; break; }
     default: v = exp10_fast(a[i]); break;
   }
   out[i] = v;

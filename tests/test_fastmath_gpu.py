@@ -110,6 +110,24 @@ def test_box_muller_kernels(eng):
     # absolute accuracy is what the normals need (the exact values cross zero)
     assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(sn, es)) <= 3e-16
     assert max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(cs, ec)) <= 3e-16
+    # the table-driven kernels of the Box-Muller transform itself (log_bm, sincos_bm: 64-row table):
+    # the logarithm on the range of the 53-bit uniforms, relatively accurate up to u -> 1; sine and
+    # cosine to the same absolute bound, from the table in LDS (14) and in device memory (15)
+    uu = np.concatenate([rng.uniform(0, 1, 6000), 1.0 - 10 ** rng.uniform(-16, -1, 1500), 2.0 ** -rng.uniform(0, 54, 1500),
+                         (np.arange(64, 129) / 128.0)[:-1], np.nextafter((np.arange(65, 129) / 128.0), 0),
+                         [2.0 ** -54, 1.0 - 2.0 ** -54, 0.5, np.nextafter(0.5, 0)]])
+    uu = uu[(uu > 0) & (uu < 1)]
+    w = ulp_err(eng.math_probe(13, uu), [mp.log(mp.mpf(float(t))) for t in uu])
+    print("log_bm: max %.2f ulp" % w)
+    assert w <= 1.5
+    vv = np.concatenate([v, np.arange(0, 129) / 128.0, np.nextafter(np.arange(1, 129) / 128.0, 0), [1.0 - 2.0 ** -54]])
+    vv = vv[vv < 1]
+    es = [mp.sin(2 * mp.pi * mp.mpf(float(t))) for t in vv]
+    ec = [mp.cos(2 * mp.pi * mp.mpf(float(t))) for t in vv]
+    ds = max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(eng.math_probe(14, vv), es))
+    dc = max(abs(float(mp.mpf(float(a)) - b)) for a, b in zip(eng.math_probe(15, vv), ec))
+    print("sincos_bm: max abs error %.2e / %.2e" % (ds, dc))
+    assert ds <= 2.5e-16 and dc <= 2.5e-16
 
 
 def test_exp2_kernels_of_the_band_loop(eng):
