@@ -268,7 +268,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // so "which parameter moves" is a scalar branch: the step changes th[blk] in place, evaluates th, and
 // a rejected lane puts the one old value back - instead of a masked update of all P parameters into a
 // copy and a P-wide select at the accept.  Same arithmetic on the moved parameter (th + z sigma),
-// bit-identical chains (tests/test_sed_gpu.py compares the two instantiations).
+// bit-identical chains (tests/test_gmh_gpu.py::test_sed_in_place_instantiation_equals_stepwise_engine and
+// the mixed-catalogue / lane-mapping tests, which compare across the instantiations).
 template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
 __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
