@@ -131,7 +131,7 @@ static int launch_form(mi355_ctx* c, const ClFormArgs& a) {
   // largest dynamic LDS opted in for this instantiation, per device
   static size_t opted[kMaxDevices] = {};
   size_t& have = opted[c->device % kMaxDevices];
-  if (lds > 64 * 1024 - kStaticTabBytes && lds > have) {
+  if (lds > 48 * 1024 && lds > have) {
     MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_form<RT, CG, MODE, NW, SYM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     have = lds;
@@ -162,7 +162,7 @@ static int launch_form_rt(mi355_ctx* c, const ClFormArgs& a) {
   return launch_form_cg<RT, CL_ROWS_MARGE>(c, a);
 }
 
-constexpr size_t kClLdsBudget = 160 * 1024 - kStaticTabBytes;   // dynamic LDS of a block: the 160 KB of a CU less the static tables (18 KB)
+constexpr size_t kClLdsBudget = 144 * 1024;   // dynamic LDS of a block, of the 160 KB per CU (the Cl kernels have no static LDS)
 
 // chisq rows / G matrices of data set d for the band powers in p->bp (or raw vectors)
 static int run_form(mi355_ctx* c, ClData* d, const double* rows_src, int64_t n, int mode, int ncal,
@@ -377,7 +377,7 @@ template <int NW, int FORM, bool RES, bool CMR = false>
 static int launch_cl_mh(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
   static size_t opted[kMaxDevices] = {};
   size_t& have = opted[c->device % kMaxDevices];
-  if (lds > 64 * 1024 - kStaticTabBytes && lds > have) {
+  if (lds > 48 * 1024 && lds > have) {
     MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_mh_run<NW, FORM, RES, CMR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     have = lds;
