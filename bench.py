@@ -256,7 +256,7 @@ def main():
         # thinned trace rows per chain: 100, fewer when the trace [rows, P, N] would pass 32 GB
         rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
         thin = max(1, args.ess_steps // rows)
-        eng.mh_run(100, thin=1)                               # allocates the trace buffers, untimed
+        eng.mh_run(rows, thin=1)                              # allocates the trace buffers (rows kept), untimed
         barrier()
         t1 = time.perf_counter()
         eng.mh_run(args.ess_steps, thin=thin)
@@ -298,7 +298,7 @@ def main():
             eng.mh_track_cov(False)
             rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
             thin = max(1, args.corr_steps // rows)
-            eng.mh_run(100, thin=1)
+            eng.mh_run(rows, thin=1)
             barrier()
             t3 = time.perf_counter()
             eng.mh_run(args.corr_steps, thin=thin)
@@ -315,7 +315,7 @@ def main():
                 "rhat_median": float(torch.nanmedian(rh).item()),
                 "rhat_lt_1p1_frac": float((torch.nan_to_num(rh, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
                 "note": "after 8000 adaptation steps (two uncorrelated and two correlated stages, fac 0.6); "
-                        "R-hat over the moments of the measured stage incl. its 100 trace-allocation steps"}}
+                        "R-hat over the moments of the measured stage incl. its trace-allocation steps"}}
 
     evals_per_launch = float(S) * C * inner                   # per GPU
     total_evals = evals_per_launch * args.steps * world
