@@ -100,6 +100,24 @@ __device__ __forceinline__ double sed_prior(const double* th, const SedConsts& k
   }
 }
 
+// The four normalised greybody models have a pure box prior with the same box for both components
+// (value 0 or 1; model.py:407-425, :491-508, :560-570, :759-769): a point that differs from a point
+// inside the box in ONE parameter - and by package()'s exchange of whole components - is inside the
+// box iff that parameter is inside its own interval.  sed_prior_one tests parameter i = v with the
+// comparisons sed_prior makes (NaN passes, as there).
+template <int MODEL>
+constexpr bool sed_prior_is_box() {
+  return MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA || MODEL == MI355_SED_M2N ||
+         MODEL == MI355_SED_M2N_LOGA;
+}
+template <int MODEL>
+__device__ __forceinline__ bool sed_prior_one(int i, double v, const SedConsts& k) {
+  const int kind = i % 3;                                  // (A or logA, beta, T) per component
+  if (kind == 2) return t_ok(v, k, true);
+  if (kind == 1) return b_ok(v, k);
+  return (MODEL == MI355_SED_M1N_LOGA || MODEL == MI355_SED_M2N_LOGA) ? true : !(v < 0);
+}
+
 // ---- package(): T1<=T2 canonicalisation, model.py:192-196, :439-443, :510-514 --------------
 template <int MODEL>
 __device__ __forceinline__ void sed_package(double* th) {

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
   int thin_ctr = 0;
   int64_t row = 0;
   double za = 0.0, zb = 0.0, ua = 0.0, ub = 0.0;   // cached Philox pairs (npn == 1)
+  bool state_ok = SINGLE && sed_prior_is_box<MODEL>() && sed_prior<MODEL>(th, a.k) > 0.0;   // current state inside the box
   double nsamp = static_cast<double>(a.nsamp0);    // samples in the moments so far (a 64-bit integer costs
                                                    // four instructions per step to convert)
 
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     double* const nw = SINGLE ? th : nwc;                  // ... or the state itself, moved in place
     double old = 0.0;                                      // SINGLE: th[blk] before the step
     bool swapped = false;                                  // SINGLE: package() exchanged the components
+    bool moved_ok = true;                                  // SINGLE, box prior: the moved parameter is inside its interval
     if constexpr (!SINGLE) {
 #pragma unroll
       for (int i = 0; i < P; ++i) nwc[i] = th[i];
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
           asm volatile("");                                // (keeps the optimizer from flattening it into P selects)
           old = th[i];
           th[i] = old + z * sg[i];                         // Proposal.py:151,156-159
+          if constexpr (sed_prior_is_box<MODEL>()) moved_ok = sed_prior_one<MODEL>(i, th[i], a.k);
         }
     } else if (EXT && a.mode != 0) {
       // z_j of the step: correlated - normal(step npn + j) for every j; rotated - normal(step npn +
@@ -499,7 +502,14 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
     else sed_package<MODEL>(nw);                           // Proposal.py:164
     // The reference evaluates the likelihood before the prior (MCMC.py:236-245); the outcome
     // (reject, keep prev) is the same with the prior tested first, which skips the evaluation.
-    const double prior = sed_prior<MODEL>(nw, a.k);
+    // SINGLE, box priors: while every lane's current state is inside the box (checked at launch entry,
+    // kept by every accepted step), the proposal is inside iff its one moved parameter is (sed_prior_one:
+    // two comparisons behind the scalar branch above instead of the ten of the full prior)
+    double prior;
+    if (SINGLE && sed_prior_is_box<MODEL>() && __builtin_amdgcn_ballot_w64(!state_ok) == 0)
+      prior = moved_ok ? 1.0 : 0.0;
+    else
+      prior = sed_prior<MODEL>(nw, a.k);
     bool accepted = false;
     double next = lnPr;
     // A non-finite proposal inside the prior box (A = inf / NaN: the box has no upper bound on A
@@ -529,6 +539,7 @@ __global__ __launch_bounds__(kBlockThreads, MI355_MH_MIN_WAVES) void k_mh_run(Mh
       if (accepted) {
         lnPr = next;
         ++nacc;                                            // :269
+        state_ok = true;                                   // an accepted point has prior > 0
       }
       if (__builtin_amdgcn_ballot_w64(swapped && !accepted) != 0) {   // rare: a wave-level branch
         asm volatile("");
