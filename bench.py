@@ -28,9 +28,10 @@ sys.path.insert(0, ROOT)
 FLOP_PER_STEP = 1342.0        # 2-comp, 8 bands, 1 transcendental = 32 FP64 FLOP
 PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vector FP64)
 # HBM bytes per chain per launch of k_mh_run<M2N>, from the PMC passes in
-# profiles/r2_bench_summary.txt (same figures as r1): (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
-# State is read and written once per launch whatever the number of inner steps.
-HBM_BYTES_PER_CHAIN_LAUNCH = 415.7
+# profiles/r2_bench_summary.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
+# State is read and written once per launch whatever the number of inner steps (415.7 B per chain);
+# the rest is the scratch of the 80 VGPRs the three-waves-per-SIMD register allocation spills.
+HBM_BYTES_PER_CHAIN_LAUNCH = 1012.0
 
 
 def _port_worker(job):
@@ -348,7 +349,7 @@ def main():
                      "note": "FP64 VALU (transcendental-bound); algorithmic FLOP = 1342 per MH step "
                              "(SURVEY 8d convention, 1 transcendental = 32 FLOP) x S*C*inner steps "
                              "per launch; traffic = HBM bytes per launch from rocprofv3 PMC "
-                             "(profiles/r2_bench_summary.txt), ~1% of the 8 TB/s roof"},
+                             "(profiles/r2_bench_summary.txt; state in and out plus register-spill scratch), ~3% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
         # fraction of sources whose worst parameter has R-hat < 1.1 (reference formula,
         # convergence.py:77-85) after adapt + warmup + timed steps
