@@ -652,7 +652,7 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, EXT, G, SINGLE>
 // No counterpart in the reference, which rebuilds model(*params)(data) at every step
 // (Likelihood.py:70-75); opt-in through mi355_mh_set_incremental.
 template <int MODEL>
-__global__ __launch_bounds__(kBlockThreads, 2) void k_mh_run_inc(MhArgs a) {
+__global__ __launch_bounds__(kBlockThreads, 3) void k_mh_run_inc(MhArgs a) {
   static_assert(MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA, "two-component models");
   constexpr int P = 6;
   constexpr bool LG = MODEL == MI355_SED_M2N_LOGA;
