@@ -271,20 +271,21 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // bit-identical chains (tests/test_gmh_gpu.py::test_sed_in_place_instantiation_equals_stepwise_engine and
 // the mixed-catalogue / lane-mapping tests, which compare across the instantiations).
 // Waves per SIMD the register allocation aims at.  Two (256 VGPRs, no spills) everywhere except in the
-// in-place lane = chain instantiation of the models measured faster with three (168 VGPRs; 80 of them
+// plain lane = chain instantiations on the fast path (in place or not) of the models measured faster with three (168 VGPRs; 80 of them
 // spill to scratch in the two-component kernel, and the third wave still wins: 29.7 -> 27.1 ms per
 // 200-step launch of C2 - the kernel waits on its own dependency chains, which a third wave fills).
 // Measured and left at two: M1N / M1N_LOGA (no change), THICK (9.9 -> 13.4 ms per 200 steps of
-// 20 000 x 64 chains), the extended sampler (50 -> 63 ms).  tools/ab_bench.sh, tools/time_models.py.
-template <int MODEL, bool EXT, int G, bool SINGLE>
+// 20 000 x 64 chains), the extended sampler (50 -> 63 ms).  Without parameter blocks (six normals a step):
+// 11.6 -> 11.2 ms per 200 steps.  tools/ab_bench.sh, tools/time_models.py, tools/time_noblock.py.
+template <int MODEL, bool FAST, bool EXT, int G>
 constexpr int mh_min_waves() {
-  return (SINGLE && !EXT && G == 1 &&
+  return (FAST && !EXT && G == 1 &&
           (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA || MODEL == MI355_SED_M1 ||
            MODEL == MI355_SED_THICK_LOGA))
              ? 3 : MI355_MH_MIN_WAVES;
 }
 template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
-__global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, EXT, G, SINGLE>())) void k_mh_run(MhArgs a) {
+__global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>())) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
   static_assert(!SINGLE || !EXT, "single-parameter blocks: plain sampler");
   constexpr int P = ModelTraits<MODEL>::P;
