@@ -30,8 +30,8 @@ PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vec
 # HBM bytes per chain per launch of k_mh_run<M2N>, from the PMC passes in
 # profiles/r2_bench_summary.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
 # State is read and written once per launch whatever the number of inner steps (415.7 B per chain);
-# the rest is the scratch of the 80 VGPRs the three-waves-per-SIMD register allocation spills.
-HBM_BYTES_PER_CHAIN_LAUNCH = 1012.0
+# the rest is the scratch of the 50 VGPRs the three-waves-per-SIMD register allocation spills.
+HBM_BYTES_PER_CHAIN_LAUNCH = 817.4
 
 
 def _port_worker(job):
