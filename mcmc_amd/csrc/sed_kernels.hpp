@@ -274,14 +274,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // plain lane = chain instantiations on the fast path (in place or not) of the models measured faster with three (168 VGPRs; 80 of them
 // spill to scratch in the two-component kernel, and the third wave still wins: 29.7 -> 27.1 ms per
 // 200-step launch of C2 - the kernel waits on its own dependency chains, which a third wave fills).
-// Measured and left at two: M1N / M1N_LOGA (no change), THICK (9.9 -> 13.4 ms per 200 steps of
-// 20 000 x 64 chains), the extended sampler (50 -> 63 ms).  Without parameter blocks (six normals a step):
+// Measured and left at two: M1N / M1N_LOGA (no change), the extended sampler (50 -> 63 ms).  THICK lost at
+// first (9.9 -> 13.4 ms per 200 steps of 20 000 x 64 chains) and gains since the file is compiled without
+// machine LICM (10.1 -> 8.9 ms).  Without parameter blocks (six normals a step):
 // 11.6 -> 11.2 ms per 200 steps.  tools/ab_bench.sh, tools/time_models.py, tools/time_noblock.py.
 template <int MODEL, bool FAST, bool EXT, int G>
 constexpr int mh_min_waves() {
   return (FAST && !EXT && G == 1 &&
           (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA || MODEL == MI355_SED_M1 ||
-           MODEL == MI355_SED_THICK_LOGA))
+           MODEL == MI355_SED_THICK || MODEL == MI355_SED_THICK_LOGA))
              ? 3 : MI355_MH_MIN_WAVES;
 }
 template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
