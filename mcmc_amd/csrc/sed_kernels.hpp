@@ -285,10 +285,22 @@ constexpr int mh_min_waves() {
            MODEL == MI355_SED_THICK || MODEL == MI355_SED_THICK_LOGA))
              ? 3 : MI355_MH_MIN_WAVES;
 }
-template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false>
+// XM = 1: the extended sampler compiled for ONE proposal - Cholesky-correlated with free-running draws,
+// lane = chain, blocks of kBlockThreads lanes (what every stage of sampler() after the first runs unless
+// noCorrelations, MCMC.py:389-403; the ESS leg of bench.py).  No run-time proposal mode, rank tables or
+// injection in the step loop, the uniform pair serves two steps (the general instantiation draws a
+// Philox block per step for it), L z accumulated column by column as the normals arrive: 1137 VALU
+// instructions per wave-step against 1390, 42.2 against 51.4 ms per 200 steps of C2.  Same draws, same
+// arithmetic as the general instantiation and the step-wise engine (tests/test_gmh_gpu.py compares
+// them bit for bit).  Measured on top of it and not kept (tools/ab_ext.sh, round 3): registers for three
+// waves per SIMD with the diagonal of L in registers so that three blocks fit a CU's LDS (41.7 - 42.7 ms
+// with 36 - 85 spilled VGPRs: at two waves VALUBusy is 92 % already, the kernel is bound by its
+// instruction count); one block of 768 lanes per CU (48 ms, average occupancy 2.2 waves per SIMD).
+template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false, int XM = -1>
 __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>())) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
   static_assert(!SINGLE || !EXT, "single-parameter blocks: plain sampler");
+  static_assert(XM == -1 || (XM == 1 && EXT && G == 1), "XM: the Cholesky-correlated extended sampler, lane = chain");
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -383,7 +395,8 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
       for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j)
-          Ll[(i * (i + 1) / 2 + j) * blockDim.x] = a.L[(static_cast<int64_t>(i) * P + j) * a.N + n];
+          Ll[(i * (i + 1) / 2 + j) * (XM == 1 ? kBlockThreads : static_cast<int>(blockDim.x))] =
+              a.L[(static_cast<int64_t>(i) * P + j) * a.N + n];
     }
   }
 
@@ -434,6 +447,29 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
           th[i] = old + z * sg[i];                         // Proposal.py:151,156-159
           if constexpr (sed_prior_is_box<MODEL>()) moved_ok = sed_prior_one<MODEL>(i, th[i], a.k);
         }
+    } else if constexpr (EXT && XM == 1) {
+      // Cholesky-correlated, free-running: normal(step NPN + j) for every j (Proposal.py:150-154), the
+      // step's uniform from the pair it shares with its neighbour
+      constexpr int NPN = (P + 1) & ~1;
+      if (t == 0 || (step & 1u) == 0) philox_uniform2(a.seed, RNG_UNIFORM, n, step >> 1, ua, ub);
+      u = (step & 1u) ? ub : ua;
+      // L z column by column, a pair of normals at a time (each row's sum still runs over j ascending
+      // from 0.0, as k_gmh_propose's): a pair is dead once its two columns are in
+      double off[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) off[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < P; j += 2) {
+        double zz[2];
+        philox_normal2(a.seed, RNG_NORMAL, n, step * (NPN / 2) + (j >> 1), bmt, zz[0], zz[1]);
+#pragma unroll
+        for (int q = 0; q < 2 && j + q < P; ++q)
+#pragma unroll
+          for (int i = j + q; i < P; ++i) off[i] += Ll[(i * (i + 1) / 2 + j + q) * kBlockThreads] * zz[q];
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        if ((mask >> i) & 1u) nw[i] += off[i] * sg[i];     // Proposal.py:153-159
     } else if (EXT && a.mode != 0) {
       // z_j of the step: correlated - normal(step npn + j) for every j; rotated - normal(step npn +
       // rank_j) for the members j of the block (injected rows: element j / element rank_j)
