@@ -27,11 +27,15 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 1342.0        # 2-comp, 8 bands, 1 transcendental = 32 FP64 FLOP
 PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vector FP64)
-# HBM bytes per chain per launch of k_mh_run<M2N>, from the PMC passes in
-# profiles/r2_bench_summary.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) / 6.4e6 chains.
-# State is read and written once per launch whatever the number of inner steps (415.7 B per chain);
-# the rest is the scratch of the 50 VGPRs the three-waves-per-SIMD register allocation spills.
+# HBM bytes per chain per launch of k_mh_run<M2N>.  NOT measured in this run: a constant taken from
+# the PMC passes of tools/prof_bench.sh over this same command (TRAFFIC_SOURCE: (2 x FETCH_SIZE [gfx950
+# correction] + WRITE_SIZE) / 6.4e6 chains), to be regenerated whenever the kernel's register
+# allocation changes.  State is read and written once per launch whatever the number of inner steps
+# (STATE_BYTES_PER_CHAIN, the algorithmic figure); the rest is the scratch of the VGPRs the
+# three-waves-per-SIMD register allocation spills.
 HBM_BYTES_PER_CHAIN_LAUNCH = 817.4
+STATE_BYTES_PER_CHAIN = 415.7
+TRAFFIC_SOURCE = "profiles/r2_bench_summary.txt"
 
 
 def _port_worker(job):
@@ -135,11 +139,16 @@ def main():
     ap.add_argument("--inner", type=int, default=200, help="MH steps per chain per launch")
     ap.add_argument("--adapt", type=int, default=2000, help="untimed stage-0 steps before newMCMC (SURVEY 8(d): 2 000)")
     ap.add_argument("--ess-steps", type=int, default=10000,
-                    help="MH steps of the (separately timed) ESS/s measurement; 0 = skip")
+                    help="MH steps of the (separately timed) ESS/s measurement with the production driver's "
+                         "uncorrelated single-parameter blocks; 0 = skip")
     ap.add_argument("--incremental-steps", type=int, default=3,
                     help="extra launches with the opt-in incremental sampler (0 = skip)")
-    ap.add_argument("--corr-steps", type=int, default=10000,
-                    help="MH steps of the correlated-proposal ESS/s measurement (one GPU only); 0 = skip")
+    ap.add_argument("--corr-steps", type=int, default=50000,
+                    help="MH steps of the correlated-proposal ESS/s measurement (one GPU only), after 18 000 "
+                         "steps of staged adaptation; 0 = skip")
+    ap.add_argument("--c3-slice-steps", type=int, default=3,
+                    help="one GPU only: launches of one GPU's slice of config C3 (1e6 sources x 32 chains) "
+                         "timed after the C2 legs - the same-shape anchor of a multi-GPU run; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     args = ap.parse_args()
@@ -192,14 +201,13 @@ def main():
             left -= min(inner, left)
         eng.mh_adapt()
 
-    rhat_s = []                                               # wall time of the R-hat of every step
+    rhat_ev = []                                              # (start, end) events of the R-hat of every step
 
     def one_step():
         eng.mh_run(inner)                                     # synchronous: the launch has finished
-        t = time.perf_counter()
-        r = D.engine_rhat(eng, Ctot=C * world)                # two kernels (+ two all-reduces on several GPUs)
-        rhat_s.append(time.perf_counter() - t)
-        return r
+        # two kernels (+ two all-reduces on several GPUs), enqueued without a host wait: the next
+        # launch starts behind the second kernel, beside the second all-reduce
+        return D.engine_rhat(eng, Ctot=C * world, timing=rhat_ev)
 
     def barrier():
         if world > 1:
@@ -210,15 +218,15 @@ def main():
     for _ in range(args.warmup):
         one_step()
     kernel_ms = []
-    del rhat_s[:]
     barrier()
+    del rhat_ev[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rhat = one_step()
         kernel_ms.append(eng.last_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    rhat_ms = 1e3 * float(np.mean(rhat_s)) if rhat_s else 0.0
+    rhat_ms = float(np.mean([a.elapsed_time(b) for a, b in rhat_ev])) if rhat_ev else 0.0
     if rank == 0:
         print("kernel ms per launch:", " ".join("%.2f" % v for v in kernel_ms), file=sys.stderr)
     if world > 1:
@@ -249,14 +257,34 @@ def main():
                         "band terms of the unchanged component kept across single-parameter steps"}}
         eng.mh_set_incremental(False)
 
-    # ESS/s (second half of BASELINE.json's metric): a separately timed run that keeps a thinned
-    # trace (100 rows per chain) in HBM, then the multi-chain BDA3 estimator on the device; per
-    # source the minimum over parameters, summed over sources and (chains being independent) ranks
-    ess_out = {}
+    # ESS/s (second half of BASELINE.json's metric): separately timed runs that keep a thinned trace
+    # (100 rows per chain) in HBM, then the multi-chain BDA3 estimator on the device; per source the
+    # minimum over parameters.  BDA3's estimate means something only where the chains of a source agree,
+    # so the rate counts the sources whose worst parameter has R-hat < 1.1 over the measured stage
+    # (reference formula, convergence.py:77-85) and says which fraction of the catalogue that is; the
+    # time is that of the whole run (every source), estimator included.
+    def ess_summary(ess, rh, seconds):
+        em = np.nanmin(np.where(np.isfinite(ess), ess, np.nan), axis=1)
+        worst = np.where(np.isfinite(rh), rh, np.inf).max(axis=1)
+        ok = worst < 1.1
+        conv = float(np.nansum(em[ok]))
+        return {"ess_per_sec": conv / seconds, "rhat_lt_1p1_frac": float(ok.mean()),
+                "rhat_median": float(np.nanmedian(rh)),
+                "ess_median_per_converged_source": float(np.nanmedian(em[ok])) if ok.any() else None,
+                "ess_per_sec_all_sources": float(np.nansum(em)) / seconds,
+                "seconds": seconds}, conv
+
+    def trace_rows():      # thinned trace rows per chain: 100, fewer when [rows, P, N] would pass 32 GB
+        return int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+
+    prod_out = {}
     if args.ess_steps > 0:
-        # thinned trace rows per chain: 100, fewer when the trace [rows, P, N] would pass 32 GB
-        rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+        # the production driver's proposal (driver.py:173-175: noCorrelations=True, doBlock=True), the
+        # configuration `value` is measured on: it mixes slowly on this workload (two barely constrained
+        # greybodies per source), few sources converge in 10 000 steps
+        rows = trace_rows()
         thin = max(1, args.ess_steps // rows)
+        eng.mh_adapt()                                        # a stage of its own: R-hat over these steps only
         eng.mh_run(rows, thin=1)                              # allocates the trace buffers (rows kept), untimed
         barrier()
         t1 = time.perf_counter()
@@ -264,40 +292,41 @@ def main():
         ess = eng.mh_ess()
         barrier()
         t_ess = time.perf_counter() - t1
-        ess_min = np.nanmin(np.where(np.isfinite(ess), ess, np.nan), axis=1)
-        tot = torch.tensor([float(np.nansum(ess_min)), t_ess], dtype=torch.float64, device=device)
+        summ, conv = ess_summary(ess, eng.rhat(), t_ess)
         if world > 1:
+            tot = torch.tensor([conv, t_ess], dtype=torch.float64, device=device)
             both = [torch.zeros_like(tot) for _ in range(world)]
             torch.distributed.all_gather(both, tot)
-            ess_total = float(sum(b[0].item() for b in both))
             t_ess = float(max(b[1].item() for b in both))
-        else:
-            ess_total = float(tot[0].item())
-        ess_out = {"ess_per_sec": ess_total / t_ess, "ess_steps": args.ess_steps, "ess_thin": thin,
-                   "ess_median_per_source": float(np.nanmedian(ess_min)),
-                   "ess_caveat": "BDA3 ESS is only meaningful for sources whose chains have converged: "
-                                 "read it together with rhat_lt_1p1_frac",
-                   "ess_note": "sum over sources of min-over-parameters ESS (BDA3 11.5 multi-chain "
-                               "estimator on the device, %d chains x %d thinned rows per source per "
-                               "GPU) / wall time of that run incl. the estimator" % (C, args.ess_steps // thin)}
+            summ["ess_per_sec"] = float(sum(b[0].item() for b in both)) / t_ess
+            summ["seconds"] = t_ess
+        summ.update({"steps": args.ess_steps, "thin": thin,
+                     "proposal": "uncorrelated single-parameter blocks, sigma = 2.4/sqrt(6) stdev (MCMC.py:379-385)",
+                     "note": "per GPU: sum over converged sources of min-over-parameters ESS (BDA3 11.5 on the "
+                             "device, %d chains x %d thinned rows per source) / wall time of the run incl. the "
+                             "estimator; R-hat per rank over its own chains" % (C, args.ess_steps // thin)})
+        prod_out = {"production_proposal_ess": summ}
 
-    # Correlated proposals (newMCMC's Cholesky factor of the chain covariance, Proposal.py:150-154)
-    # in the fused kernel's extended instantiation: mixing per second beside the production
-    # configuration (driver.py:173-175 runs noCorrelations=True, which is what `value` measures)
+    # Correlated proposals (newMCMC's Cholesky factor of the chain covariance, MCMC.py:389-403,
+    # Proposal.py:150-154) in the fused kernel's instantiation for them, adapted in stages until the
+    # chains of most sources agree (tests/test_mixing_gpu.py has the same schedule): the ESS/s figure of
+    # the line.  driver.py:173-175 itself runs noCorrelations=True, which is what `value` measures.
     corr_out = {}
     if args.corr_steps > 0 and world == 1:
         eng.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                             randomize_start=True, track_cov=True)
         if eng.mh_fused_active:
-            eng.mh_run(2000)
+            barrier()
+            t_ad = time.perf_counter()
+            eng.mh_run(2000)                                  # stage 0: the driver's widths, doBlock
             eng.mh_adapt_corr(no_correlations=True)
-            eng.mh_run(2000)
-            for n in (1000, 3000):
+            eng.mh_run(4000)
+            for n in (2000, 10000):                           # correlated stages, all parameters at once
                 eng.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
                 eng.mh_run(n)
             eng.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
             eng.mh_track_cov(False)
-            rows = int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+            rows = trace_rows()
             thin = max(1, args.corr_steps // rows)
             eng.mh_run(rows, thin=1)
             barrier()
@@ -307,16 +336,52 @@ def main():
             ess_c = eng.mh_ess()
             barrier()
             t_corr = time.perf_counter() - t3
-            rh = torch.from_numpy(eng.rhat())
-            em = np.nanmin(np.where(np.isfinite(ess_c), ess_c, np.nan), axis=1)
-            corr_out = {"correlated_proposals": {
-                "ess_per_sec": float(np.nansum(em)) / t_corr, "ess_median_per_source": float(np.nanmedian(em)),
-                "steps": args.corr_steps, "evals_per_s": float(S) * C * args.corr_steps / (k_corr * 1e-3),
-                "kernel": "k_mh_run<M2N, fast, extended>", "kernel_ms": k_corr,
-                "rhat_median": float(torch.nanmedian(rh).item()),
-                "rhat_lt_1p1_frac": float((torch.nan_to_num(rh, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
-                "note": "after 8000 adaptation steps (two uncorrelated and two correlated stages, fac 0.6); "
-                        "R-hat over the moments of the measured stage incl. its trace-allocation steps"}}
+            summ, _ = ess_summary(ess_c, eng.rhat(), t_corr)
+            summ.update({"steps": args.corr_steps, "thin": thin, "adapt_steps": 18000, "adapt_seconds": t3 - t_ad,
+                         "ess_per_sec_incl_adaptation": summ["ess_per_sec"] * t_corr / (t_corr + t3 - t_ad),
+                         "evals_per_s": float(S) * C * args.corr_steps / (k_corr * 1e-3),
+                         "kernel": "k_mh_run<M2N, fast, extended, Cholesky-correlated>", "kernel_ms": k_corr,
+                         "kernel_ms_per_200_steps": k_corr * 200.0 / args.corr_steps,
+                         "proposal": "Cholesky-correlated, all parameters per step, sigma = 0.6 stdev",
+                         "note": "after 18 000 adaptation steps (two uncorrelated and two correlated stages); "
+                                 "R-hat over the moments of the measured stage incl. its trace-allocation steps"})
+            corr_out = {"correlated_proposals": summ, "ess_per_sec": summ["ess_per_sec"],
+                        "ess_rhat_lt_1p1_frac": summ["rhat_lt_1p1_frac"],
+                        "ess_note": "ESS/s of the correlated-proposal leg (see correlated_proposals), counted over "
+                                    "the sources with R-hat < 1.1 only"}
+    if not corr_out and prod_out:
+        corr_out = {"ess_per_sec": prod_out["production_proposal_ess"]["ess_per_sec"],
+                    "ess_rhat_lt_1p1_frac": prod_out["production_proposal_ess"]["rhat_lt_1p1_frac"],
+                    "ess_note": "ESS/s of the production proposal (see production_proposal_ess), counted over "
+                                "the sources with R-hat < 1.1 only"}
+
+    # One GPU's slice of config C3 (1e6 sources x 32 chains: what every rank of the multi-GPU run holds)
+    # on this one GPU: the same-shape anchor for a scaling curve whose N = 1 point is C2
+    c3_out = {}
+    if args.c3_slice_steps > 0 and world == 1 and config == "C2":
+        S3, C3 = 1000000, 32
+        nu3, d3, sig3, _ = synth.sed_catalogue(S3)
+        eng.sed_load("M2N", np.full(S3, nu3.shape[1], np.int32), nu3, d3, sig3)
+        eng.mh_init(C3, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6), randomize_start=True)
+        eng.mh_run(inner)
+        eng.mh_adapt()
+        eng.mh_run(inner)
+        ev3, k3 = [], []
+        D.engine_rhat(eng, Ctot=C3)
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(args.c3_slice_steps):
+            eng.mh_run(inner)
+            k3.append(eng.last_kernel_ms)
+            D.engine_rhat(eng, Ctot=C3, timing=ev3)
+        barrier()
+        t_c3 = time.perf_counter() - t4
+        c3_out = {"c3_slice": {"sources": S3, "chains_per_source": C3, "launches": args.c3_slice_steps,
+                               "evals_per_s": float(S3) * C3 * inner * args.c3_slice_steps / t_c3,
+                               "ms_per_step": 1e3 * t_c3 / args.c3_slice_steps, "kernel_ms": float(np.mean(k3)),
+                               "rhat_ms_per_step": float(np.mean([a.elapsed_time(b) for a, b in ev3])),
+                               "note": "one GPU's share of C3 (1e6 x 256 over 8 GPUs, chain-sharded) run alone: "
+                                       "divide a multi-GPU value by N times this evals_per_s, not by the C2 value"}}
 
     evals_per_launch = float(S) * C * inner                   # per GPU
     total_evals = evals_per_launch * args.steps * world
@@ -345,11 +410,14 @@ def main():
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS,
                      "traffic": HBM_BYTES_PER_CHAIN_LAUNCH * S * C,
+                     "traffic_source": "constant (not measured in this run): rocprofv3 PMC passes of this command, "
+                                       + TRAFFIC_SOURCE,
+                     "traffic_algorithmic": STATE_BYTES_PER_CHAIN * S * C,
                      "kernel": "k_mh_run<M2N>", "kernel_ms": k_ms,
                      "note": "FP64 VALU (transcendental-bound); algorithmic FLOP = 1342 per MH step "
                              "(SURVEY 8d convention, 1 transcendental = 32 FLOP) x S*C*inner steps "
-                             "per launch; traffic = HBM bytes per launch from rocprofv3 PMC "
-                             "(profiles/r2_bench_summary.txt; state in and out plus register-spill scratch), ~3% of the 8 TB/s roof"},
+                             "per launch; traffic = HBM bytes per launch (chain state in and out plus "
+                             "register-spill scratch), ~3% of the 8 TB/s roof"},
         "rhat_median": float(torch.nanmedian(rhat).item()),
         # fraction of sources whose worst parameter has R-hat < 1.1 (reference formula,
         # convergence.py:77-85) after adapt + warmup + timed steps
@@ -359,9 +427,10 @@ def main():
     }
     if args.dump_rhat and rank == 0:
         np.save(args.dump_rhat, rhat.cpu().numpy())
-    out.update(ess_out)
-    out.update(inc_out)
     out.update(corr_out)
+    out.update(prod_out)
+    out.update(inc_out)
+    out.update(c3_out)
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:

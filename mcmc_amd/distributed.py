@@ -80,23 +80,41 @@ def gelman_rubin_allreduce(partial, finish, C_local, P, S, device, group=None, C
     return out.t().contiguous(), Ctot
 
 
-def engine_rhat(engine, group=None, Ctot=None):
+def engine_rhat(engine, group=None, Ctot=None, timing=None):
     """R-hat of every loaded source over the chains of all ranks in `group` (chain-sharded
     layout); with one rank this equals Engine.rhat().  Ctot: chains per source over all ranks
     when every rank knows it (saves a collective and a host round trip per call; all ranks must
-    pass it or none).  Returns a [S,P] CUDA tensor."""
+    pass it or none).  Returns a [S,P] CUDA tensor.
+
+    Nothing here waits on the host: the engine's HIP stream (mi355_stream) and torch's current
+    stream - the one the collectives run on - wait for each other through events, and the last
+    step (sqrt((W+B)/W), convergence.py:77-85) runs on torch's stream, so the engine's stream is
+    free again after the second partial-sum kernel: the next mi355_mh_run is enqueued behind that
+    kernel and runs beside the second all-reduce.  The caller synchronises torch's stream (or uses
+    the tensor on it) before reading the result on the host.
+    timing: a list that receives (start, end) torch events around the whole computation."""
     device = torch.device("cuda", engine.device)
+    cur = torch.cuda.current_stream(device)
+    eng_stream = torch.cuda.ExternalStream(int(engine.stream), device=device)
+    if timing is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(eng_stream)
 
     def partial(pass_, gmean, out):
-        torch.cuda.current_stream(device).synchronize()      # gmean written by torch
+        eng_stream.wait_stream(cur)                           # gmean / out come from torch's stream
         engine.rhat_partial(pass_, out.data_ptr(), gmean.data_ptr() if gmean is not None else None)
-        engine.sync()                                         # engine stream -> visible to torch
+        cur.wait_stream(eng_stream)                           # ... which reads the sums after the kernel
 
     def finish(sums, Ctot, out):
-        torch.cuda.current_stream(device).synchronize()
-        engine.rhat_finish(sums.data_ptr(), Ctot, out.data_ptr())
-        engine.sync()
+        within = sums[1] / float(Ctot)                        # mean of the chain variances, :77
+        between = sums[0] / (float(Ctot) - 1.0)               # ddof=1 variance of the chain means, :78
+        torch.sqrt((within + between) / within, out=out)
+        out.masked_fill_(~(within > 0.0), float("nan"))       # :81-85
 
     rhat, _ = gelman_rubin_allreduce(partial, finish, engine.C, engine.P, engine.S, device, group,
                                      Ctot=Ctot)
+    if timing is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(cur)
+        timing.append((ev0, ev1))
     return rhat
