@@ -463,6 +463,23 @@ int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t 
 
 using namespace mi355;
 
+namespace mi355 {
+// BP = q.K + BP0 of n chains into p->bp: k_cl_bandpower stages 16 chains' bin amplitudes in LDS,
+// 128 B per bin - beyond the 48 KB a kernel gets unasked (384 bins) the launch raises its limit
+// (kClMaxBins bins = 128 KB; the reference has no limit, no data set comes near this one)
+constexpr int kClMaxBins = 1024;
+static int launch_bandpower(mi355_ctx* c, ClProblem* p, ClData* d, int64_t n, const double* q_pm) {
+  const size_t lds = static_cast<size_t>(p->npar) * 16 * sizeof(double);
+  if (lds > 48 * 1024)
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_bandpower),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256), lds, c->stream, n,
+                     p->npar, d->nb, d->nbp, q_pm, d->K.p, d->krange.p, d->bp0.p, p->bp.p);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace mi355
+
 extern "C" {
 
 int mi355_cl_load(mi355_ctx* c, int32_t ndata, const mi355_cl_dataset* data) {
@@ -586,8 +603,8 @@ int mi355_cl_set_binning(mi355_ctx* c, int32_t nCl, const int32_t* nbins, const 
   }
   MI355_REQUIRE(seen_max == lmax, "lmax=%d but the largest binned multipole is %d: pass "
                 "shapefun[:, :lmax+1] for that lmax", lmax, seen_max);
-  MI355_REQUIRE(ib <= 384, "%d bins: the band-power kernel stages at most 384 bin amplitudes per "
-                "chain in LDS", ib);
+  MI355_REQUIRE(ib <= kClMaxBins, "%d bins: the band-power kernel stages at most %d bin amplitudes per "
+                "chain in LDS", ib, kClMaxBins);
   p->nCl = nCl;
   p->npar = ib;
   p->lmax = lmax;
@@ -612,10 +629,7 @@ int mi355_cl_lnlike_dev_async(mi355_ctx* c, int64_t n, const double* q_dev, doub
   int first = 1;
   for (auto& d : p->data) {
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
-    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
-                       static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
-                       d->nbp, q_dev, d->K.p, d->krange.p, d->bp0.p, p->bp.p);
-    MI355_HIP(hipGetLastError());
+    if (launch_bandpower(c, p, d.get(), n, q_dev)) return -2;
     int rc = dataset_from_bp(c, d.get(), p->bp.p, n, lnL_dev, first ? 0 : 1, nullptr);
     if (rc) return rc;
     first = 0;
@@ -706,10 +720,7 @@ int mi355_cl_bandpowers(mi355_ctx* c, int32_t idata, int32_t what, int64_t n, co
   if (what == 0) {
     if (to_bandmajor(c, in, n, p->npar, p->npar, p->q_host_layout, p->q_pm)) return -2;
     if (p->bp.alloc(static_cast<size_t>(n) * d->nbp)) return -2;
-    hipLaunchKernelGGL(k_cl_bandpower, dim3(static_cast<unsigned>(ceil_div64(n, 16))), dim3(256),
-                       static_cast<size_t>(p->npar) * 16 * sizeof(double), c->stream, n, p->npar, d->nb,
-                       d->nbp, p->q_pm.p, d->K.p, d->krange.p, d->bp0.p, p->bp.p);
-    MI355_HIP(hipGetLastError());
+    if (launch_bandpower(c, p, d, n, p->q_pm.p)) return -2;
   } else {
     int rc = bp_from_cl(c, d, n, in, rows, L);
     if (rc) return rc;

@@ -86,9 +86,12 @@ __host__ __device__ inline size_t cl_mh_table_doubles(int nbp, int kmax, int nbe
   return static_cast<size_t>(nbp) * 4 * kmax + static_cast<size_t>(5 + cl_mh_bfac_rows(nbeam)) * nbp + nbp / 8 + 1 +
          nbp / 16 + 1;                                     // + the K ranges (int32 pairs)
 }
-// ... and of the resident copy of its N^-1 (RES kernels, full covariance)
+// ... and of the resident copy of its N^-1 (RES kernels, full covariance): kClMhSlackRows zeroed rows
+// behind it for the fetches past its end (4 rows per k-step of prefetch depth kClMhResPF)
+constexpr int kClMhResPF = 4;
+constexpr int kClMhSlackRows = 4 * kClMhResPF;
 __host__ __device__ inline size_t cl_mh_matrix_doubles(int nbp, int has_corr) {
-  return has_corr ? static_cast<size_t>(nbp + 16) * cl_mh_nstride(nbp) : 0;
+  return has_corr ? static_cast<size_t>(nbp + kClMhSlackRows) * cl_mh_nstride(nbp) : 0;
 }
 
 // doubles of dynamic LDS the kernel needs (host and device agree through this one function)
@@ -242,10 +245,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
       if (D0.has_corr) {
         const int ns = cl_mh_nstride(nbp), gs = D0.f.nstride;
         const double* src = D0.sym ? D0.f.nsym : D0.f.ninv;
-        for (int e = tid; e < nbp * nbp; e += NT) p[(e / nbp) * ns + (e % nbp)] = src[(e / nbp) * gs + (e % nbp)];
+        // the whole copy, padding columns and the kClMhSlackRows slack rows included (zero there: the
+        // form fetches its prefetch depth past the end, and what it fetches must not be garbage)
+        for (int e = tid; e < (nbp + kClMhSlackRows) * ns; e += NT) {
+          const int r = e / ns, cc = e - r * ns;
+          p[e] = (r < nbp && cc < nbp) ? src[r * gs + cc] : 0.0;
+        }
         D0.f.ninv = D0.f.nsym = p;
         D0.f.nstride = ns;
-        p += static_cast<size_t>(nbp + 16) * ns;           // 16 rows of slack: the form fetches ahead
+        p += static_cast<size_t>(nbp + kClMhSlackRows) * ns;   // slack rows: the form fetches ahead
       }
     }
     {
@@ -422,7 +430,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RES) ? 1 : 2) void k_cl_mh_run
     f.n = CB;
     f.rows = static_cast<int64_t>(CB) * D.rows_per_chain;
     f.out = fout;
-    cl_mh_form<NW, FORM, RES ? 4 : 8, TAS, MAS>(D, f, tile);   // streamed matrices: fetched 8 k-steps ahead
+    static_assert(4 * kClMhResPF <= kClMhSlackRows, "resident N^-1: slack rows cover the prefetch depth");
+    cl_mh_form<NW, FORM, RES ? kClMhResPF : 8, TAS, MAS>(D, f, tile);   // streamed matrices: fetched 8 k-steps ahead
     __syncthreads();
     CLMH_TICK(2);
     if (tid < CB) {

@@ -238,13 +238,14 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
   MI355_HIP(hipSetDevice(c->device));
   const int P = g->pb.P;
   const int64_t N = c->N;
-  if (g->cov_on) g->cov_nsamp += nsteps;
   if (fused_kind(c) == 2) {
     // SED: the fused kernel's extended instantiation (sed_kernels.hpp) - every proposal mode and
     // the co-moments at the one-launch rate; uploads, trace and counters are sed_mh_run's
     sync_block_masks(c);
-    return sed_mh_run(c, nsteps, thin, inj_n, inj_u, g->mode, g->mode != GMH_UNCORR ? g->L.p : nullptr,
-                      g->cov_on ? g->comom.p : nullptr);
+    const int rc = sed_mh_run(c, nsteps, thin, inj_n, inj_u, g->mode, g->mode != GMH_UNCORR ? g->L.p : nullptr,
+                              g->cov_on ? g->comom.p : nullptr);
+    if (rc == 0 && g->cov_on) g->cov_nsamp += nsteps;      // counted like c->nsamp: after the run succeeded
+    return rc;
   }
   if (inj_n) {
     const size_t nn = static_cast<size_t>(nsteps) * N * P, nu = static_cast<size_t>(nsteps) * N;
@@ -278,6 +279,7 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     c->step_total += nsteps;
     c->stage_step += nsteps;
     c->nsamp += nsteps;
+    if (g->cov_on) g->cov_nsamp += nsteps;
     MI355_HIP(hipStreamSynchronize(c->stream));
     return 0;
   }
@@ -325,6 +327,7 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
   c->step_total += nsteps;
   c->stage_step += nsteps;
   c->nsamp += nsteps;
+  if (g->cov_on) g->cov_nsamp += nsteps;
   MI355_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -343,9 +343,16 @@ def writeTab(ret, fname, names=None, nodat=False, plain=False):
             f.write(" ".join("%21s" % (c.decode() if plain else c) for c in row) + "\n")
 
 
-def writeTabAll(ret123, fbase, ext=".npy", nodat=False):
-    """driver.py:463-475: one file fbase<i><ext> per non-empty run"""
+def writeTabAll(ret123, fbase, ext=".npy", nodat=False, plain=True):
+    """driver.py:463-475: one file fbase<i><ext> per non-empty run.  Tables with bare cells by default,
+    which is what readtab() reads back (plain=False: the reference's Python-3 text with b'...' cells,
+    see writeTab).  With nodat=True the tables must have been made with nodat=True as well, or the
+    header would have fewer columns than the rows (writeTab keeps that quirk of the reference for its
+    byte-parity mode; here it is refused)."""
     for k, r in enumerate(ret123):
         if len(r) > 0:
-            writeTab(r, fbase + str(k) + ext, nodat=nodat)
+            if nodat and r["dat"].size:
+                raise ValueError("nodat=True on a table that holds its data columns: build it with "
+                                 "postprocess(..., nodat=True)")
+            writeTab(r, fbase + str(k) + ext, nodat=nodat, plain=plain)
     return ret123
