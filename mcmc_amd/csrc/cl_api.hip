@@ -5,6 +5,7 @@
 
 #include "cl_kernels.hpp"
 #include "cl_mh_kernels.hpp"
+#include "cl_mhw_kernels.hpp"
 #include "problems.hpp"
 
 namespace mi355 {
@@ -32,7 +33,8 @@ struct ClProblem {
   // per-call scratch
   DevBuf<double> q_host_layout, q_pm, bp, form, lnl, tmp_in, tmp_out;
   // fused Metropolis-Hastings kernel (cl_mh_kernels.hpp), planned by mi355_cl_set_binning
-  int mh_nw = 0;                   // waves per block; 0: the problem needs the step-wise engine
+  bool mh_filled = false;          // mh[] describes the loaded data sets (plan_fused)
+  int mh_nw = 0;                   // waves per block of k_cl_mh_run; 0: that kernel does not serve the problem
   int mh_nbp_max = 0, mh_fout = 9, mh_tile_doubles = 0;
   ClMhData mh[kClMhMaxData] = {};
   DevBuf<ClMhArgs> mh_args;        // the kernel reads its arguments from device memory
@@ -283,14 +285,16 @@ static int form_nw(int nbp) { return (nbp >> 4) <= 4 ? 4 : 8; }
 
 static void plan_fused(ClProblem* p) {
   p->mh_nw = 0;
+  p->mh_filled = false;
   if (p->data.empty() || p->data.size() > static_cast<size_t>(kClMhMaxData)) return;
   int nw = 0, nbp_max = 0, fout = 9;
+  bool block_kernel = true;                        // k_cl_mh_run serves the problem (k_cl_mh_wave: cl_mhw_plan)
   for (size_t i = 0; i < p->data.size(); ++i) {
     ClData* d = p->data[i].get();
     const FormPlan f = plan_for(d);
-    if (f.rows_per_chain > kClGrid) return;        // 121 points per chain: the batched kernels win
+    if (f.rows_per_chain > kClGrid) block_kernel = false;   // 121 points per chain: not in k_cl_mh_run
     if (d->has_corr) {
-      if (nw && nw != form_nw(d->nbp)) return;     // one block size serves every data set
+      if (nw && nw != form_nw(d->nbp)) block_kernel = false;   // one block size serves every data set
       nw = form_nw(d->nbp);
     }
     if (d->nbp > nbp_max) nbp_max = d->nbp;
@@ -324,10 +328,62 @@ static void plan_fused(ClProblem* p) {
     m.sym = (d->has_corr && f.mode != CL_ROWS_TRIPLE && (d->nbp >> 4) >= 8) ? 1 : 0;
   }
   if (!nw) nw = 4;
+  p->mh_filled = true;
   p->mh_nbp_max = nbp_max;
   p->mh_fout = fout;
   p->mh_tile_doubles = static_cast<int>((form_lds_bytes(nbp_max, 16, nw) + 7) / 8);
-  p->mh_nw = nw;
+  p->mh_nw = block_kernel ? nw : 0;
+}
+
+// Plan of the wave-per-16-chains kernel (cl_mhw_kernels.hpp), which takes over from k_cl_mh_run where
+// it applies: one data set with correlated errors and a MARGE form (any marginalisation grid, the
+// 11 x 11 one included), parameters and bands within its register budget.  Waves per block: as few as
+// give every CU a block (a wave never waits for another one, so small jobs spread over the CUs),
+// up to kClMhwMaxWaves; N^-1 resident in LDS when it fits beside the waves' own regions.
+struct ClMhwPlan {
+  int ok = 0, nct_t = 0, ms = 0, sym = 0, res = 0, waves = 1, rep = 1, sb = 1;
+  size_t lds = 0;
+};
+static bool cl_mh_block_ok(const ClProblem* p, int P, int nblock, int npn);   // k_cl_mh_run serves the problem
+static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int64_t N, int comom = 1) {
+  ClMhwPlan r;
+  static const int mode = [] { const char* e = getenv("MI355_CLMH_WAVE"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || !p->mh_filled || p->data.size() != 1) return r;   // (MI355_CLMH_WAVE: 0 never, 1 wherever it applies)
+  const ClData* d = p->data[0].get();
+  const FormPlan f = plan_for(d);
+  const int nct = d->nbp >> 4;
+  if (!d->has_corr || f.mode != CL_ROWS_MARGE || P > 4 * kClMhwSlots || nct > 8) return r;
+  constexpr int kCUs = 256;
+  const int64_t tiles = ceil_div64(N, kClMhChains);        // 16-chain samplers
+  const bool grid = f.rows_per_chain > 1;
+  // Small jobs without a grid: a wave alone on its SIMD walks a step's whole latency chain, and the
+  // block-per-16-chains kernel, which shares a step out over four waves, is faster (6.5 against 10.7 us
+  // per step at 4096 chains, nb = 64; the wave kernel wins from 0.75 waves per SIMD up: 11.5 against
+  // 17.0 us at 16 384 chains, 31 against 65 at 65 536).  With a grid the replicas fill the SIMDs.
+  if (mode != 1 && !grid && tiles < 3 * kCUs && cl_mh_block_ok(p, P, nblock, npn)) return r;
+  r.ms = kClMhwSlots;
+  r.nct_t = nct <= 4 ? 4 : 8;
+  r.sym = nct >= 8 ? 1 : 0;
+  r.sb = cl_mhw_cache_steps(npn);
+  if (grid)
+    while (r.rep < kClMhwMaxWaves && tiles * r.rep * 2 <= 8 * kCUs && r.rep * 2 <= f.rows_per_chain) r.rep *= 2;   // up to two waves per SIMD
+  int tpb = static_cast<int>(std::min<int64_t>(kClMhwMaxWaves / r.rep, std::max<int64_t>(1, ceil_div64(tiles, kCUs))));
+  const size_t per_wave = cl_mhw_wave_doubles(P, nblock, npn, r.sb, comom, grid);
+  const size_t xchg = grid ? cl_mhw_xchg_doubles(f.rows_per_chain) : 0;
+  for (; tpb >= 1; --tpb)                          // (fewer chains per block before giving up)
+    for (int res = 1; res >= 0; --res) {
+      if (res && r.nct_t > 4) continue;            // (the resident copy has the 4-tile kernels' compile-time stride)
+      const size_t lds = (cl_mhw_shared_doubles(P, r.nct_t, nct, d->kmax, f.nbeam, res) +
+                          static_cast<size_t>(tpb) * (r.rep * per_wave + xchg)) * 8;
+      if (lds <= kClLdsBudget) {
+        r.ok = 1;
+        r.res = res;
+        r.lds = lds;
+        r.waves = tpb * r.rep;
+        return r;
+      }
+    }
+  return r;
 }
 
 // Plan of a fused run: LDS bytes and whether the data set lives in LDS for the launch.  Resident
@@ -367,10 +423,16 @@ static ClMhLds cl_mh_plan_lds(const ClProblem* p, int P, int nblock, int npn, in
   return r;
 }
 
+static bool cl_mh_block_ok(const ClProblem* p, int P, int nblock, int npn) {
+  if (!p->mh_nw) return false;
+  if (P > kClMhSlots * (64 * p->mh_nw / kClMhChains)) return false;   // parameters per thread in registers
+  return cl_mh_plan_lds(p, P, nblock, npn, 1 << 30).bytes <= kClLdsBudget;
+}
+
 int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn) {
-  if (!c || !c->cl || !c->cl->binned || !c->cl->mh_nw) return 0;
-  if (P > kClMhSlots * (64 * c->cl->mh_nw / kClMhChains)) return 0;   // parameters per thread in registers
-  return cl_mh_plan_lds(c->cl, P, nblock, npn, 1 << 30).bytes <= kClLdsBudget ? c->cl->mh_nw : 0;
+  if (!c || !c->cl || !c->cl->binned) return 0;
+  if (cl_mhw_plan(c->cl, P, nblock, npn, int64_t{1} << 30).ok) return 1;   // the wave-per-16-chains kernel
+  return cl_mh_block_ok(c->cl, P, nblock, npn) ? c->cl->mh_nw : 0;
 }
 
 template <int NW, int FORM, bool RES, bool CMR = false>
@@ -430,10 +492,69 @@ static int launch_cl_mh_form(mi355_ctx* c, const ClMhArgs& a, size_t lds) {
   return -1;
 }
 
+template <int NCT, int MS, bool SYM, bool RES, bool GRID>
+static int launch_cl_mhw(mi355_ctx* c, const ClMhArgs& a, const ClMhwPlan& plan) {
+  static size_t opted[kMaxDevices] = {};
+  size_t& have = opted[c->device % kMaxDevices];
+  if (plan.lds > 48 * 1024 && plan.lds > have) {
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cl_mh_wave<NCT, MS, SYM, RES, GRID>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.lds)));
+    have = plan.lds;
+  }
+  ClProblem* p = c->cl;
+  if (p->mh_args.alloc(1)) return -2;
+  MI355_HIP(hipMemcpyAsync(p->mh_args.p, &a, sizeof(ClMhArgs), hipMemcpyHostToDevice, c->stream));
+  MI355_HIP(hipStreamSynchronize(c->stream));
+  const unsigned grid = static_cast<unsigned>(ceil_div64(a.g.N, static_cast<int64_t>(kClMhChains) * (plan.waves / plan.rep)));
+  hipLaunchKernelGGL((k_cl_mh_wave<NCT, MS, SYM, RES, GRID>), dim3(grid), dim3(64 * plan.waves), plan.lds, c->stream,
+                     static_cast<const ClMhArgs*>(p->mh_args.p));
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int NCT, bool SYM>
+static int launch_cl_mhw_form(mi355_ctx* c, const ClMhArgs& a, const ClMhwPlan& plan) {
+  constexpr int MS = kClMhwSlots;
+  const bool grid = a.data[0].rows_per_chain > 1;
+  if constexpr (NCT == 4) {                              // (the resident copy of N^-1: up to 64 bands)
+    if (plan.res)
+      return grid ? launch_cl_mhw<NCT, MS, SYM, true, true>(c, a, plan) : launch_cl_mhw<NCT, MS, SYM, true, false>(c, a, plan);
+  }
+  return grid ? launch_cl_mhw<NCT, MS, SYM, false, true>(c, a, plan) : launch_cl_mhw<NCT, MS, SYM, false, false>(c, a, plan);
+}
+
+static int cl_mhw_run(mi355_ctx* c, ClMhArgs& a, const ClMhwPlan& plan) {
+  a.sb = plan.sb;
+  a.rep = plan.rep;
+  a.resident = plan.res;
+  a.tables = 1;
+  if (plan.nct_t == 4) return launch_cl_mhw_form<4, false>(c, a, plan);
+  return plan.sym ? launch_cl_mhw_form<8, true>(c, a, plan) : launch_cl_mhw_form<8, false>(c, a, plan);
+}
+
 int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t nkeep) {
   ClProblem* p = c->cl;
   const int nw = cl_mh_fused_nw(c, g.pb.P, g.nblock, g.npn);
   MI355_REQUIRE(nw > 0, "cl_mh_run: the loaded Cl problem has no fused kernel");
+  const ClMhwPlan wplan = cl_mhw_plan(p, g.pb.P, g.nblock, g.npn, g.N, g.comom != nullptr);
+  if (wplan.ok) {
+    ClMhArgs a{};
+    a.g = g;
+    a.ndata = 1;
+    a.data[0] = p->mh[0];
+    a.nbp_max = p->mh_nbp_max;
+    a.weights = p->weights.p;
+    a.margenorm = p->margenorm;
+    a.nsteps = nsteps;
+    a.thin = thin;
+    a.nkeep = nkeep;
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
+    const int rc = cl_mhw_run(c, a, wplan);
+    if (rc) return rc;
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    if (!c->capturing) c->ev_valid = true;
+    return 0;
+  }
   const ClMhLds plan = cl_mh_plan_lds(p, g.pb.P, g.nblock, g.npn, g.N);
   ClMhArgs a{};
   a.g = g;
@@ -452,7 +573,8 @@ int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t 
   a.nkeep = nkeep;
   const size_t lds = plan.bytes;
   if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
-  const int rc = nw == 4 ? launch_cl_mh_form<4>(c, a, lds) : launch_cl_mh_form<8>(c, a, lds);
+  MI355_REQUIRE(p->mh_nw > 0, "cl_mh_run: no fused kernel serves this run");
+  const int rc = p->mh_nw == 4 ? launch_cl_mh_form<4>(c, a, lds) : launch_cl_mh_form<8>(c, a, lds);
   if (rc) return rc;
   if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
   if (!c->capturing) c->ev_valid = true;

@@ -20,8 +20,9 @@ namespace mi355 {
 // ln for the offset-lognormal deltas in the MFMA kernel's row staging: the library's short
 // branch-free kernel (a few ulp; |delta| errors of ~1e-15 against ln(C+x) ~ 8) with the IEEE end
 // cases the reference relies on (ln 0 = -inf, :389).
+template <bool SK = false>
 __device__ __forceinline__ double cl_log(double z) {
-  const double l = log_fast(z);
+  const double l = log_fast<SK>(z);
   return (z > 0.0) ? ((z < __builtin_inf()) ? l : z) : ((z == 0.0) ? -__builtin_inf() : __builtin_nan(""));
 }
 

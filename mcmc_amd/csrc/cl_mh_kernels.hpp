@@ -67,6 +67,7 @@ struct ClMhArgs {
   int resident;              // 1: the (single) data set's N^-1 is copied into LDS at launch too
   int tables;                // 1: single data set whose tables and compact K live in LDS (FORM != ANY)
   int sb;                    // steps whose Philox draws one refill of the draw cache covers
+  int rep;                   // k_cl_mh_wave: waves (replicas) per 16 chains that share out a marginalisation grid
   const double* weights;     // [11] margeweights
   double margenorm;
   int64_t nsteps;

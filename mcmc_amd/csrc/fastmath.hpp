@@ -143,6 +143,14 @@ __device__ __forceinline__ double fma_k(double p, double z, double c) {
   return r;
 }
 
+// ... and with the constant in a scalar register pair: for kernels that have no vector registers to
+// spare for polynomial constants (cl_mhw_kernels.hpp)
+__device__ __forceinline__ double fma_ks(double p, double z, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+  return r;
+}
+
 // ---- table-driven 2^y (the band loop of the SED fast path) ------------------------------------
 // y = k/2048 + f with k = round(2048 y) taken from the low mantissa bits of y + 1.5 2^41 (no
 // v_rndne / v_cvt), |f| <= 2^-12:  2^y = 2^(k >> 11) * T[k & 2047] * (1 + f P(f)),  T[i] = 2^(i/2048)
@@ -272,6 +280,8 @@ __device__ __forceinline__ double div_fast(double a, double b) { return div_rcp(
 // ---- Box-Muller kernels ------------------------------------------------------------------------
 // ln(u) for normal positive u (the Box-Muller radius only needs a few ulp): u = m 2^e with
 // m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), ln m = 2s + s z (2/3 + 2/5 z + ... ) with z = s^2.
+// SK: the polynomial's constants in scalar instead of vector registers (same operations, same bits)
+template <bool SK = false>
 __device__ __forceinline__ double log_fast(double u) {
   int e = __builtin_amdgcn_frexp_exp(u);
   double m = __builtin_amdgcn_frexp_mant(u);               // [0.5, 1)
@@ -281,17 +291,18 @@ __device__ __forceinline__ double log_fast(double u) {
   const double f = m - 1.0;
   const double s = div_fast(f, 2.0 + f);
   const double z = s * s;
+  auto hs = [](double p, double zz, double c) { return SK ? fma_ks(p, zz, c) : fma_k(p, zz, c); };
   double r = 2.0 / 23.0;
-  r = fma_k(r, z, 2.0 / 21.0);
-  r = fma_k(r, z, 2.0 / 19.0);
-  r = fma_k(r, z, 2.0 / 17.0);
-  r = fma_k(r, z, 2.0 / 15.0);
-  r = fma_k(r, z, 2.0 / 13.0);
-  r = fma_k(r, z, 2.0 / 11.0);
-  r = fma_k(r, z, 2.0 / 9.0);
-  r = fma_k(r, z, 2.0 / 7.0);
-  r = fma_k(r, z, 2.0 / 5.0);
-  r = fma_k(r, z, 2.0 / 3.0);
+  r = hs(r, z, 2.0 / 21.0);
+  r = hs(r, z, 2.0 / 19.0);
+  r = hs(r, z, 2.0 / 17.0);
+  r = hs(r, z, 2.0 / 15.0);
+  r = hs(r, z, 2.0 / 13.0);
+  r = hs(r, z, 2.0 / 11.0);
+  r = hs(r, z, 2.0 / 9.0);
+  r = hs(r, z, 2.0 / 7.0);
+  r = hs(r, z, 2.0 / 5.0);
+  r = hs(r, z, 2.0 / 3.0);
   const double lm = fma(s * z, r, s + s);
   const double fe = static_cast<double>(e);
   return fma(fe, kLn2Hi, fma(fe, kLn2Lo, lm));
@@ -304,7 +315,7 @@ __device__ __forceinline__ double log2_fast(double u) {
   const bool lo = m < 0x1.6a09e667f3bcdp-1;
   m = lo ? m + m : m;
   e = lo ? e - 1 : e;
-  return fma(log_fast(m), kLog2e, static_cast<double>(e));  // |ln m| <= ln(2)/2: no cancellation
+  return fma(log_fast<>(m), kLog2e, static_cast<double>(e));  // |ln m| <= ln(2)/2: no cancellation
 }
 
 // sin(2 pi u), cos(2 pi u) for u in [0, 1): quarter-turn reduction (exact), then the fdlibm

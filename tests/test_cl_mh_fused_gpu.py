@@ -1,5 +1,7 @@
-"""The fused binnedCl Metropolis-Hastings kernel (csrc/cl_mh_kernels.hpp: a whole mh_run in one
-launch, chain state in LDS) against the step-wise engine it replaces (five launches per step):
+"""The fused binnedCl Metropolis-Hastings kernels (a whole mh_run in one launch: csrc/cl_mhw_kernels.hpp,
+one wave per 16 chains with everything of a step in registers, for a single data set with correlated
+errors and x-factors; csrc/cl_mh_kernels.hpp, a block per 16 chains, for the other shapes) against the
+step-wise engine they replace (five launches per step):
 same draws, same arithmetic, so the chains must be identical bit for bit - in every proposal mode
 of Proposal.py:127-164, for every shape of ClData_CosmoMC.calcLnLike (:267-315: plain, 11-point
 calibration grid, analytic marginalisation, uncorrelated errors, two data sets, symmetrised-matrix
@@ -23,6 +25,15 @@ def problem(kind):
         return model, [d], truth
     if kind == "beam11":                                  # 11-point beam grid (calib exactly 0)
         model, d, truth = RC.synth_cl_problem(nb=24, npar=5, calib=0.0, beam=0.02, lmax=700, seed=7)
+        return model, [d], truth
+    if kind == "grid121":                                 # 11 x 11 calibration x beam grid (:317-372): the wave kernel
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=5)
+        return model, [d], truth
+    if kind == "grid121w":                                # ... on 5 column tiles and 20 bins
+        model, d, truth = RC.synth_cl_problem(nb=72, npar=20, calib=0.05, beam=0.02, lmax=1500, seed=21)
+        return model, [d], truth
+    if kind == "sym128":                                  # 8 column tiles: the symmetrised matrix in the wave kernel
+        model, d, truth = RC.synth_cl_problem(nb=128, npar=24, calib=0.05, beam=0.0, lmax=2400, seed=22)
         return model, [d], truth
     if kind == "analytic":                                # no x-factors: analytic calib + beam (TRIPLE rows)
         model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=8,
@@ -115,9 +126,10 @@ def same(a, b):
             assert np.array_equal(x, y, equal_nan=True), k
 
 
-@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "analytic", "diag", "two", "sym144", "wide96", "densek", "big384"])
+@pytest.mark.parametrize("kind", ["plain", "calib11", "beam11", "grid121", "grid121w", "sym128", "analytic", "diag", "two",
+                                  "sym144", "wide96", "densek", "big384"])
 def test_fused_equals_stepwise_every_likelihood_shape(kind):
-    C = 40 if kind not in ("sym144", "big384") else 19    # not a multiple of the 16 chains of a block
+    C = 40 if kind not in ("sym144", "big384", "sym128") else 19    # not a multiple of the 16 chains of a block
     same(run(kind, True, "uncorr_block", C, False), run(kind, False, "uncorr_block", C, False))
 
 
@@ -126,7 +138,7 @@ def test_fused_equals_stepwise_every_proposal_mode(mode):
     same(run("plain", True, mode, 37, True), run("plain", False, mode, 37, True))
 
 
-@pytest.mark.parametrize("kind", ["beam11", "calib11", "p32", "diag", "analytic", "two", "wide96"])
+@pytest.mark.parametrize("kind", ["beam11", "calib11", "p32", "grid121", "sym128", "diag", "analytic", "two", "wide96"])
 def test_fused_comoments_equal_stepwise(kind):
     """Running co-moments (covar(), MCMC.py:310-340) and the newMCMC stage they feed: in registers for
     the resident 4-wave kernels up to 32 parameters (odd and even counts, every form), in HBM
@@ -161,13 +173,16 @@ def test_dense_k_band_powers_match_the_oracle():
     np.testing.assert_allclose(got, ref, rtol=1e-12)
 
 
-def test_problems_beyond_the_fused_kernel_fall_back_to_the_stepwise_engine():
-    """121 marginalisation points per chain: batched kernels (step-wise engine), by design."""
+def test_problems_beyond_the_fused_kernels_fall_back_to_the_stepwise_engine():
+    """More data sets than the fused kernels' argument block describes: the step-wise engine."""
     from oracle import refcl as RC
     from mcmc_amd import Engine
-    model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=5)
+    data = []
+    for k in range(5):
+        model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.0, beam=0.0, lmax=700, seed=5 + k)
+        data.append(d)
     with Engine(seed=1) as eng:
-        eng.cl_load([d])
+        eng.cl_load(data)
         eng.cl_set_binning(model.bins, model.shapefun)
         eng.mh_init_problem("cl", 8, truth, np.full(6, 0.02), param_blocks=np.arange(6))
         assert not eng.mh_fused_active
