@@ -361,6 +361,11 @@ static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int
   // per step at 4096 chains, nb = 64; the wave kernel wins from 0.75 waves per SIMD up: 11.5 against
   // 17.0 us at 16 384 chains, 31 against 65 at 65 536).  With a grid the replicas fill the SIMDs.
   if (mode != 1 && !grid && tiles < 3 * kCUs && cl_mh_block_ok(p, P, nblock, npn)) return r;
+  // The full 11 x 11 grid: a step is 121 forms, throughput work once the chip is full, and the launch-per-
+  // step engine's form kernel is the faster one from there (per step, fused against step-wise: 188 / 197 us
+  // at 2048 chains, 197 / 259 at 4096, 434 / 473 at 8192, 915 / 803 at 16 384).  The 11-point grids stay
+  // fused at every size (25 / 56 us at 4096 chains, 73 / 133 at 16 384, 258 / 364 at 65 536).
+  if (mode != 1 && f.rows_per_chain > kClGrid && tiles > 2 * kCUs) return r;
   r.ms = kClMhwSlots;
   r.nct_t = nct <= 4 ? 4 : 8;
   r.sym = nct >= 8 ? 1 : 0;

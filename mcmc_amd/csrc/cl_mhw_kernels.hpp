@@ -225,12 +225,23 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
   const int kmax = D0.kmax;
   const int ncal = D0.f.ncal, nbeam = D0.f.nbeam;
   const bool has_x = D0.f.has_x != 0;
+  int ks0[NCT];                                            // first k-step of every tile's bin range
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) ks0[ct] = ct < nct ? __builtin_amdgcn_readfirstlane(kr_t[2 * ct]) : 0;
   int blk = g.blk;
   int ts = 0;                                              // t % sb
   int thin_ctr = 0;
   int64_t row_next = 0;
 
+#ifdef MI355_CLMH_PROF
+  long long wt[6] = {0, 0, 0, 0, 0, 0};
+  long long wc = clock64();
+#define MHW_TICK(k) do { const long long now_ = clock64(); wt[k] += now_ - wc; wc = now_; } while (0)
+#else
+#define MHW_TICK(k) do {} while (0)
+#endif
   for (int64_t t = 0; t < a.nsteps; ++t) {
+    MHW_TICK(5);
     // ---- getNewParams (Proposal.py:127-164) + prior (binnedClModel.py:125-132) into rnew ----
     const int64_t step = g.step + t;
     const uint64_t base = static_cast<uint64_t>(step) * g.npn;
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
     }
     const bool pbad = ((__builtin_amdgcn_ballot_w64(neg) >> cl) & 0x0001000100010001ull) != 0;
 
+    MHW_TICK(0);
     // ---- band powers, transposed: BP[16 ct + g + 4 i][c] = BP0 + sum_b K[b][band] q[b][c] ----
     // (the proposal goes through LDS: a tile's k-steps start at the run-time bin 4 ks0(ct); kmax k-steps
     // for every tile, rows beyond a tile's range or bin P - 1 are zeros of the compact K, as cl_bp_tile)
@@ -323,29 +335,40 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
     for (int m = 0; m < MS; ++m)
       if (G * m + grp < P) thn[(G * m + grp) * CB + cl] = rnew[m];
     cl_mhw_sync();
+    // (k-step by k-step over all the tiles at once: NCT independent accumulators, the band-power
+    // registers themselves, instead of one tile's dependent chain after the other)
     double bpv[NK];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      if (ct < nct) {                                      // uniform
-        const int ks0 = __builtin_amdgcn_readfirstlane(kr_t[2 * ct]);
-        double4_t acc;
+    for (int s = 0; s < NK; ++s) bpv[s] = bp0_l[4 * s];    // (the padded table: zeros beyond band nb - 1)
+    {
+      const auto qp = as_ptr<3>(thn) + cl;
+      const auto kp0 = Kc + grp * 16 + cl;
+#pragma unroll 2
+      for (int u = 0; u < kmax; ++u) {
+        double kf[NCT], qf[NCT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (ct * 16 + grp + 4 * i < nb) ? bp0_l[4 * (4 * ct + i)] : 0.0;
-        const auto kp = Kc + (static_cast<size_t>(ct) * (4 * kmax) + grp) * 16 + cl;
-        const auto qp = as_ptr<3>(thn) + cl;
-#pragma unroll 4
-        for (int u = 0; u < kmax; ++u) {
-          const int bq = 4 * (ks0 + u) + grp;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kp[(4 * u) * 16], qp[(bq < P ? bq : P - 1) * CB], acc, 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int ctc = ct < nct ? ct : 0;               // (tiles beyond the data set's: tile 0 again, dropped)
+          const int bq = 4 * (ks0[ct] + u) + grp;
+          kf[ct] = kp0[(static_cast<size_t>(ctc) * (4 * kmax) + 4 * u) * 16];
+          qf[ct] = qp[(bq < P ? bq : P - 1) * CB];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bpv[4 * ct + i] = (ct * 16 + grp + 4 * i < nb) ? acc[i] : 0.0;
-      } else {
+        for (int ct = 0; ct < NCT; ++ct) {
+          double4_t acc = double4_t{bpv[4 * ct], bpv[4 * ct + 1], bpv[4 * ct + 2], bpv[4 * ct + 3]};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[ct], qf[ct], acc, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bpv[4 * ct + i] = 0.0;
+          for (int i = 0; i < 4; ++i) bpv[4 * ct + i] = acc[i];
+        }
       }
     }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        bpv[4 * ct + i] = (ct < nct && ct * 16 + grp + 4 * i < nb) ? bpv[4 * ct + i] : 0.0;
 
+    MHW_TICK(1);
     // ---- chi-square of every marginalisation point (ClData_CosmoMC.py:317-372) ----
     // the row's delta (cl_form_tile's row staging, :333-338, :383-392), band 4 s + g of chain c, four
     // logarithms at a time (the scheduling barriers keep the compiler from interleaving all NK chains,
@@ -373,73 +396,106 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the tiles in cl_form_tile's order: virtual wave by virtual wave, pass by pass.  Rolled loops
-      // (one tile body; nothing of one tile for the compiler to hoist out of the step loop and spill).
+      MHW_TICK(2);
+      // the tiles in cl_form_tile's order: virtual wave by virtual wave, pass by pass - two virtual
+      // waves at a time, their two MFMA chains interleaved (a chain alone waits out the dependent
+      // latency of every MFMA).  Rolled loops (one body; nothing of one tile for the compiler to hoist
+      // out of the step loop and spill).
       double total = 0.0;
 #pragma nounroll
-      for (int w = 0; w < NWREF; ++w) {
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int w = 0; w < NWREF; w += 2) {
+        double part[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma nounroll
         for (int ps = 0; ps < NPASS; ++ps) {
-          const int ct = cl_mhw_tile<NWREF, NCT, SYM>(w, ps);
-          if (ct < 0 || ct >= nct) continue;               // uniform
-          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+          int ct[2];
+          bool on[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            ct[h] = cl_mhw_tile<NWREF, NCT, SYM>(w + h, ps);
+            on[h] = ct[h] >= 0 && ct[h] < nct;             // uniform
+            if (!on[h]) ct[h] = 0;                         // (computed on tile 0, dropped)
+          }
+          if (!on[0] && !on[1]) continue;
+          double4_t acc[2] = {double4_t{0.0, 0.0, 0.0, 0.0}, double4_t{0.0, 0.0, 0.0, 0.0}};
           // k-steps: 4 (ct + 1) of the symmetrised matrix; else all NK - those beyond the padded band
           // count meet delta = 0 (and zero rows of the resident copy; the streamed copy's zero slack row)
-          const int nks = SYM ? 4 * (ct + 1) : NK;         // a multiple of 4
-          auto frag = [&](int ks) -> double {
+          const int nks0 = SYM ? 4 * (ct[0] + 1) : NK, nks1 = SYM ? 4 * (ct[1] + 1) : NK;   // multiples of 4
+          const int nksm = nks0 > nks1 ? nks0 : nks1;
+          auto frag = [&](int h, int ks) -> double {
             if constexpr (RES) {
-              return nm_l[ks * (4 * NST) + ct * 16];
+              return nm_l[ks * (4 * NST) + ct[h] * 16];
             } else {
               const int r0 = 4 * ks;                       // rows 4 ks + g; beyond the matrix: its first slack row
-              const bool in = SYM || r0 + 3 < nbp;         // (nbp is a multiple of 16: a k-step is inside or outside)
+              const bool in = r0 + 3 < nbp;                // (nbp is a multiple of 16: a k-step is inside or outside)
               const char* base = reinterpret_cast<const char*>(SYM ? D0.f.nsym : D0.f.ninv) +
-                                 (static_cast<size_t>(in ? r0 : nbp) * nstride + ct * 16) * 8;
+                                 (static_cast<size_t>(in ? r0 : nbp) * nstride + ct[h] * 16) * 8;
               const uint32_t off = in ? nm_off : static_cast<uint32_t>(cl) * 8u;
               return *(const __attribute__((address_space(1))) double*)((const __attribute__((address_space(1))) char*)base + off);
             }
           };
-          double cur[4], nxt[4];
+          double cur[2][4], nxt[2][4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) cur[u] = frag(u);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[h][u] = frag(h, u);
 #pragma unroll
           for (int s0 = 0; s0 < NK; s0 += 4) {
-            if (s0 < nks) {                                // uniform (a compile-time truth without SYM)
-              if (s0 + 4 < nks) {
+            if (s0 < nksm) {                               // uniform (a compile-time truth without SYM)
+              if (s0 + 4 < nksm) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) nxt[u] = frag(s0 + 4 + u);
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) nxt[h][u] = frag(h, s0 + 4 + u);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              // (a symmetrised tile's k-steps beyond its own 4 (ct + 1) run on zeroed operands only when
+              // its partner is longer: SYM tiles take the branch below per half)
+              if (!SYM || s0 < nks0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0][u], dv[s0 + u], acc[0], 0, 0, 0);
+              }
+              if (!SYM || s0 < nks1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[1][u], dv[s0 + u], acc[1], 0, 0, 0);
               }
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], dv[s0 + u], acc, 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
+              for (int h = 0; h < 2; ++h)
 #pragma unroll
-              for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+                for (int u = 0; u < 4; ++u) cur[h][u] = nxt[h][u];
             }
           }
-          // delta of the tile's own bands (registers 4 ct .. 4 ct + 3, ct uniform: a select chain)
-          double dct[4];
+          // delta of a tile's own bands (registers 4 ct .. 4 ct + 3, ct uniform: a select chain)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            dct[i] = dv[i];
+          for (int h = 0; h < 2; ++h) {
+            double dct[4];
 #pragma unroll
-            for (int c2 = 1; c2 < NCT; ++c2) dct[i] = (ct == c2) ? dv[4 * c2 + i] : dct[i];
+            for (int i = 0; i < 4; ++i) {
+              dct[i] = dv[i];
+#pragma unroll
+              for (int c2 = 1; c2 < NCT; ++c2) dct[i] = (ct[h] == c2) ? dv[4 * c2 + i] : dct[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (on[h] && ct[h] * 16 + grp + 4 * i < nb) part[h][i] = fma(acc[h][i], dct[i], part[h][i]);
           }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (ct * 16 + grp + 4 * i < nb) part[i] = fma(acc[i], dct[i], part[i]);
         }
         // cl_form_tile's butterfly over the 16 columns lc = g + 4 i: xor 1, 2 across lanes, xor 4, 8 in registers
-        double b4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const double a1 = part[i] + __shfl_xor(part[i], 16);
-          b4[i] = a1 + __shfl_xor(a1, 32);
+        for (int h = 0; h < 2; ++h) {
+          double b4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double a1 = part[h][i] + __shfl_xor(part[h][i], 16);
+            b4[i] = a1 + __shfl_xor(a1, 32);
+          }
+          const double tw = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+          total = (w + h == 0) ? tw : total + tw;
         }
-        const double tw = (b4[0] + b4[1]) + (b4[2] + b4[3]);
-        total = (w == 0) ? tw : total + tw;
       }
+      MHW_TICK(3);
       return total;
     };
     double chisq = 0.0;
@@ -466,6 +522,7 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
         chisq = cl_marge11<3>(xb, CB, a.weights, a.margenorm);   // one row or one column of the grid
       }
     }
+    MHW_TICK(4);
     const double lnl = 0.0 + (-(chisq / 2));               // :315, as cl_combine_chain
 
     // ---- accept / reject (MCMC.py:236-279), the same decision in the chain's four lanes ----
@@ -549,6 +606,12 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
     ts = (ts + 1 == a.sb) ? 0 : ts + 1;
   }
 
+#ifdef MI355_CLMH_PROF
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+    printf("clmhw block %d steps %lld (ticks per step): propose %lld bp %lld rows(ln) %lld form %lld marge %lld accept+moments %lld\n",
+           blockIdx.x, (long long)a.nsteps, wt[0] / a.nsteps, wt[1] / a.nsteps, wt[2] / a.nsteps, wt[3] / a.nsteps,
+           wt[4] / a.nsteps, wt[5] / a.nsteps);
+#endif
   // ---- state back to HBM ----
   cl_mhw_sync();
   if (valid && writer) {
