@@ -19,57 +19,52 @@ class DataSizeError(Exception):                                      # :30-31
     pass
 
 
+# proposal width of the orientation parameter: position-angle form / (x, y) form of the model
+_ANGLE_STEP = {False: 0.6, True: 0.2}
+
+
+def _start_and_steps(mod, bmap, angle_step):
+    """Starting point and proposal widths of one map, in the model's packaged layout
+    (centre(2), widths(2), orientation, amplitude, (offset, cos theta, phi)).  What each entry is
+    made of is the reference's recipe (:160-216): a tenth of the prior box for centre and widths;
+    the map's own moments, the widths held inside [sigMin, sigMax]; half the data range for the
+    amplitude, and twice the range of the pixels within one width of the centre as its step - wide
+    enough to cross from the no-beam mode to the beam."""
+    box = np.subtract(mod.centerMax, mod.centerMin)
+    tenth = (box[0] / 10, box[1] / 10)
+    cx, cy, vx, vy = bmap.stats(sigcut=0.0)[:4]                       # device: k_beam_stats
+    widths = np.clip(np.sqrt([vx, vy]), mod.sigMin, mod.sigMax)
+    core = bmap.d[(np.abs(bmap.x - cx) < widths[0]) & (np.abs(bmap.y - cy) < widths[1])]
+    start = ((cx, cy), widths, 0, (bmap.d.max() - bmap.d.min()) / 2, (0, 1, 0))
+    steps = (tenth, tenth, angle_step, 2 * (core.max() - core.min()), (0.3, 0, 0))
+    return start, steps
+
+
 def setup_sampler(data, xyrange, useNormalizedBeam=False, rangeScale=None, sigminmax=(3, 8),
                   verbose=True):
     """-> (like, prop_sigmas, start_params) for the maps in `data` (a list of BeamData), the
-    centre prior spanning `xyrange` (a data set, or sequences of coordinates).  :124-236"""
-    np.set_printoptions(precision=4, linewidth=150, suppress=True)
+    centre prior spanning `xyrange` (a data set, or sequences of coordinates).  Interface and
+    results of the reference's :124-236 (pinned by tests/golden/setup_sampler_g12.json); the prior
+    box, the width limits and the parameter blocks are class state of the model, as there."""
     if not useNormalizedBeam:
         raise NotImplementedError(
             "setup_sampler(useNormalizedBeam=False): GaussianBeamModel2D with the amplitude-"
             "marginalising base Likelihood has no device path; use useNormalizedBeam=True "
             "(OffsetNormalizedBeamModel + NormalizedBeamLikelihood, the reference's beam runs)")
+    np.set_printoptions(precision=4, linewidth=150, suppress=True)
     mod = OffsetNormalizedBeamModel.OffsetNormalizedBeamModel
     like = NormalizedBeamLikelihood.NormalizedBeamLikelihood(data=data, model=mod)
-    use_xy = OffsetNormalizedBeamModel.use_xy
-
-    mod.setxyRange(xyrange, scale=rangeScale)     # class variables: the prior of all instances
+    mod.setxyRange(xyrange, scale=rangeScale)
     mod.sigMin, mod.sigMax = sigminmax
-    like.setdata(data)                            # (the device snapshot of the prior follows)
+    mod.paramBlocks, mod.nBlock = list(range(7)), 7               # the gradient (mu, phi) stays fixed
+    like.setdata(data)                                            # device snapshot of the prior
+    start_params, prop_sigmas = _start_and_steps(mod, data[0], _ANGLE_STEP[bool(OffsetNormalizedBeamModel.use_xy)])
     if verbose:
         print('setting sigMin, sigMax=', mod.sigMin, mod.sigMax)
-    dx = (mod.centerMin[0], mod.centerMax[0])
-    dy = (mod.centerMin[1], mod.centerMax[1])
-    delx = dx[1] - dx[0]
-    dely = dy[1] - dy[0]
-    if verbose:
         print('center min, max=', mod.centerMin, mod.centerMax)
-
-    prop_sigmas = ((delx / 10, dely / 10), (delx / 10, dely / 10), 0.6)
-    if use_xy:
-        prop_sigmas = ((delx / 10, dely / 10), (delx / 10, dely / 10), 0.2)
-    if verbose:
         print("averaging over all data for starting point")
-    stats = data[0].stats(sigcut=0.0)             # device: k_beam_stats
-    startsigs = np.minimum([np.sqrt(stats[2]), np.sqrt(stats[3])], mod.sigMax)
-    startsigs = np.maximum(startsigs, mod.sigMin)
-    start_params = ((stats[0], stats[1]), startsigs, 0)
-
-    # amplitude: a proposal wide enough to "jump the barrier" (:199-206)
-    x = data[0].x - stats[0]
-    y = data[0].y - stats[1]
-    d = data[0].d
-    dctr = d[np.logical_and(abs(x) < startsigs[0], abs(y) < startsigs[1])]
-    prop_sigmas += 2 * (max(dctr) - min(dctr)),
-    prop_sigmas += (0.3, 0, 0),                   # offset, gradient [cos(theta), phi]
-    start_params += (max(data[0].d) - min(data[0].d)) / 2,
-    start_params += (0, 1, 0),
-
-    mod.paramBlocks = [0, 1, 2, 3, 4, 5, 6]       # offset only: mu, phi stay fixed (:220-221)
-    mod.nBlock = 7
-    if verbose:
-        print(("Starting point:  " + mod.fmtstring) % tuple(mod.unpackage(start_params)))
-        print(("Starting sigmas: " + mod.fmtstring) % tuple(mod.unpackage(prop_sigmas)))
+        for title, pars in (("Starting point:  ", start_params), ("Starting sigmas: ", prop_sigmas)):
+            print((title + mod.fmtstring) % tuple(mod.unpackage(pars)))
     return like, prop_sigmas, start_params
 
 

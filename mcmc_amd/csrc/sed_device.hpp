@@ -275,6 +275,64 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     const double amp = FNid / FNiF;
     if (derived) derived[0] = amp;
     return 0.5 * FNid * amp;
+  } else if constexpr (MODEL == MI355_SED_M2) {
+    // SEDLikelihood2 (likelihood.py:35-74): the two un-normalised greybodies at every band through the
+    // table-driven 2^z kernels - prefac nu_b^-beta nu^(3+beta) / expm1(x) = pre 2^(e log2 nu - y) / (1 - 2^-y),
+    // as the one-component branch above - then the 2 x 2 normal equations and their Cholesky solve
+    // exactly as the exact path does them (same operation order: the system's condition number, up to
+    // 1e6 and beyond on real photometry, multiplies whatever the band fluxes err by, so the solve
+    // itself adds nothing).  No upper temperature limit in this model's prior either (model.py:160-174):
+    // points beyond Tmax take the exact path.
+    const double T1 = th[1], T2 = th[3];
+    if (T1 > k.Tmax || T2 > k.Tmax) return sed_lnlike<MODEL>(th, B, k, derived);
+    const double e1 = 3.0 + th[0], e2 = 3.0 + th[2];
+    const double pre1 = k.prefac * pow2_prelog(-th[0], k.ln_nub_hi, k.ln_nub_lo);
+    const double pre2 = k.prefac * pow2_prelog(-th[2], k.ln_nub_hi, k.ln_nub_lo);
+    const double rT1 = rcp_nr2(T1), rT2 = rcp_nr2(T2);     // T >= Tmin > 0 on this path
+    double m00 = 0, m01 = 0, m11 = 0, b0 = 0, b1 = 0;
+    auto add = [&](double g1, double g2, double w, double d) {
+      const double g1w = g1 * w, g2w = g2 * w;
+      m00 = fma(g1w, g1, m00); m01 = fma(g1w, g2, m01); m11 = fma(g2w, g2, m11);
+      b0 = fma(g1w, d, b0);    b1 = fma(g2w, d, b1);
+    };
+    int j = 0;
+    // two bands at a time (their eight exponentials interleaved); rows nb <= j < nbu have weight 0
+    // and finite fluxes: they add exact zeros
+    for (; j + 1 < B.nbu; j += 2) {
+      const double hna = B.hnu2(j), lha = B.lhi(j), hnb = B.hnu2(j + 1), lhb = B.lhi(j + 1);
+      const double y1a = hna * rT1, y2a = hna * rT2, y1b = hnb * rT1, y2b = hnb * rT2;
+      const double z[8] = {fma(e1, lha, -y1a), -y1a, fma(e2, lha, -y2a), -y2a,
+                           fma(e1, lhb, -y1b), -y1b, fma(e2, lhb, -y2b), -y2b};
+      double pw[8];
+      exp2_tab_n<8>(z, B.e2t, pw);
+      const double g1a = div_fast(pre1 * pw[0], 1.0 - pw[1]), g2a = div_fast(pre2 * pw[2], 1.0 - pw[3]);
+      const double g1b = div_fast(pre1 * pw[4], 1.0 - pw[5]), g2b = div_fast(pre2 * pw[6], 1.0 - pw[7]);
+      add(g1a, g2a, B.w(j), B.d(j));
+      add(g1b, g2b, B.w(j + 1), B.d(j + 1));
+    }
+    for (; j < B.nbu; ++j) {
+      const double hn = B.hnu2(j), lh = B.lhi(j);
+      const double y1 = hn * rT1, y2 = hn * rT2;
+      const double z[4] = {fma(e1, lh, -y1), -y1, fma(e2, lh, -y2), -y2};
+      double pw[4];
+      exp2_tab_n<4>(z, B.e2t, pw);
+      add(div_fast(pre1 * pw[0], 1.0 - pw[1]), div_fast(pre2 * pw[2], 1.0 - pw[3]), B.w(j), B.d(j));
+    }
+    double z0 = __builtin_nan(""), z1 = z0;                // not positive definite: rejected, as the exact path
+    if (m00 > 0.0) {
+      const double r00 = 1.0 / sqrt(m00);
+      const double u01 = m01 * r00;
+      const double d11 = m11 - u01 * u01;
+      if (d11 > 0.0) {
+        const double r11 = 1.0 / sqrt(d11);
+        const double y0 = b0 * r00;
+        const double y1 = fma(-u01, y0, b1) * r11;
+        z1 = y1 * r11;
+        z0 = fma(-u01, z1, y0) * r00;
+      }
+    }
+    if (derived) { derived[0] = z0; derived[1] = z1; }
+    return 0.5 * (b0 * z0 + b1 * z1);
   } else if constexpr (MODEL == MI355_SED_THICK) {
     // A (1 - e^-tau)/(1 - e^-tau_b) (nu/nu_b)^3 expm1(x_b)/expm1(x), tau = (nu/nu0/nu_rescale)^beta
     // (model.py:649-657).  The optical depth in base 2: log2 tau = beta (log2(nu/nu_b) - c0) with

@@ -277,12 +277,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_mh_start(MhArgs a) {
 // Measured and left at two: M1N / M1N_LOGA (no change), the extended sampler (50 -> 63 ms).  THICK lost at
 // first (9.9 -> 13.4 ms per 200 steps of 20 000 x 64 chains) and gains since the file is compiled without
 // machine LICM (10.1 -> 8.9 ms).  Without parameter blocks (six normals a step):
-// 11.6 -> 11.2 ms per 200 steps.  tools/ab_bench.sh, tools/time_models.py, tools/time_noblock.py.
+// 11.6 -> 11.2 ms per 200 steps.  SEDLikelihood2 on its fast path (round 3): 8.15 -> 7.76 ms per 200 steps
+// of 20 000 x 64 chains.  tools/ab_bench.sh, tools/time_models.py, tools/time_noblock.py.
 template <int MODEL, bool FAST, bool EXT, int G>
 constexpr int mh_min_waves() {
   return (FAST && !EXT && G == 1 &&
           (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA || MODEL == MI355_SED_M1 ||
-           MODEL == MI355_SED_THICK || MODEL == MI355_SED_THICK_LOGA))
+           MODEL == MI355_SED_M2 || MODEL == MI355_SED_THICK || MODEL == MI355_SED_THICK_LOGA))
              ? 3 : MI355_MH_MIN_WAVES;
 }
 // XM = 1: the extended sampler compiled for ONE proposal - Cholesky-correlated with free-running draws,

@@ -24,55 +24,58 @@ def GaussPDF(x, mean=0, stdev=1):
 def getallsamples(MCMC, burn=0, stride=1, derived=True):
     """samples (+ derived parameters as extra columns) of a sampler object, or the array itself;
     rows burn::stride, a burn in (0,1) being a fraction of the chain (getdist_ahj.py:30-41)."""
-    try:
-        s = MCMC.samples
-        if derived and MCMC.nDerived:
-            s = np.hstack([s, MCMC.derived])
-    except AttributeError:
-        s = MCMC
-    if 0 < burn < 1:
-        burn = int(burn * len(s))
-    return s[burn::stride]
+    rows = getattr(MCMC, "samples", None)
+    if rows is None:
+        rows = MCMC                                  # a plain [nsample, nparam] array
+    elif derived and MCMC.nDerived:
+        rows = np.hstack([rows, MCMC.derived])
+    first = int(burn * len(rows)) if 0 < burn < 1 else burn
+    return rows[first::stride]
 
 
-def _max_like(MCMC, s, lnLike):
-    """The best sample and the reference's consistency check of the stored lnPr against a fresh
-    evaluation (getdist_ahj.py:54-65, :188-199); returns (lnLike, maxlnLike, maxLikeParams)."""
-    try:
-        if lnLike is None:
-            lnLike = MCMC.lnPr
-    except AttributeError:
-        lnLike = None
-    if lnLike is None:
-        return None, None, None
-    maxlnLike = max(lnLike)
-    maxLikeParams = s[np.argmax(lnLike)]
-    maxLProb = MCMC.like.lnLike(maxLikeParams) + np.log(MCMC.like.model.prior(*maxLikeParams))
-    maxLchi2 = MCMC.like.chi2(maxLikeParams)
-    return lnLike, maxlnLike, (maxLikeParams, maxLProb, maxLchi2)
+class _Best:
+    """The best sample of a chain and the re-evaluated posterior there.  `of()` returns None when
+    there is no lnLike to rank by (a bare array and no `lnLike` argument)."""
+
+    def __init__(self, chain, rows, lnlike):
+        at = int(np.argmax(lnlike))
+        self.lnlike, self.params = max(lnlike), rows[at]
+        like = chain.like
+        self.chi2 = like.chi2(self.params)
+        self.again = like.lnLike(self.params) + np.log(like.model.prior(*self.params))
+
+    @classmethod
+    def of(cls, chain, rows, lnlike):
+        if lnlike is None:
+            lnlike = getattr(chain, "lnPr", None)
+        return None if lnlike is None else cls(chain, rows, lnlike)
+
+    def check(self):
+        # the stored lnPr against a fresh evaluation, to the reference's 1 % (:60-62, :194-196)
+        if not abs(1. - self.again / self.lnlike) < 0.01:
+            raise AssertionError("different likelihood calculations differ: %f != %f"
+                                 % (self.again, self.lnlike))
+
+    def result(self):
+        return (self.lnlike, self.params)
 
 
 def printvals(MCMC, params=None, lnLike=None, derived=True):
-    """Print the best sample and mean +- stdev (ddof=0) of every parameter; returns
-    (maxlnLike, maxLikeParams).  getdist_ahj.py:44-76."""
-    s = getallsamples(MCMC, derived=derived)
-    lnLike, maxlnLike, best = _max_like(MCMC, s, lnLike)
-    if lnLike is not None:
-        maxLikeParams, maxLProb, maxLchi2 = best
-        print("chi2 at max = %f" % (maxLchi2,))
-        assert abs(1. - maxLProb / maxlnLike) < 0.01, \
-            "different likelihood calculations differ: %f != %f" % (maxLProb, maxlnLike)
-        print('Max ln likelihood %f at parameters:' % maxlnLike)
-        print(maxLikeParams)
-    else:
-        # the reference goes on to use maxLikeParams and fails with NameError (:70)
+    """Best sample, then mean +- stdev (ddof=0) beside the best value of each parameter in
+    `params` (default: all); returns (maxlnLike, maxLikeParams).  Printed lines and return value
+    of getdist_ahj.py:44-76."""
+    rows = getallsamples(MCMC, derived=derived)
+    best = _Best.of(MCMC, rows, lnLike)
+    if best is None:                               # (the reference goes on and fails with NameError, :70)
         raise ValueError("printvals needs lnLike (or a sampler object with .lnPr)")
-    if params is None:
-        params = range(s.shape[1])
-    for param, ML in zip(params, maxLikeParams):
-        s1 = s.T[param]
-        print('mean = %g +- %g | ML = %g' % (s1.mean(), s1.std(), ML))
-    return (maxlnLike, maxLikeParams)
+    print("chi2 at max = %f" % (best.chi2,))
+    best.check()
+    print('Max ln likelihood %f at parameters:' % best.lnlike)
+    print(best.params)
+    columns = range(rows.shape[1]) if params is None else params
+    for col, at_best in zip(columns, best.params):
+        print('mean = %g +- %g | ML = %g' % (rows[:, col].mean(), rows[:, col].std(), at_best))
+    return best.result()
 
 
 def histgrid(MCMC, params=None, nbins=30, labels=None, lnLike=None, quiet=False, derived=True,
@@ -81,17 +84,14 @@ def histgrid(MCMC, params=None, nbins=30, labels=None, lnLike=None, quiet=False,
     and stride only select what would be drawn), the consistency check, the same printed lines;
     returns (maxlnLike, maxLikeParams), or None for a bare array without lnLike.  Nothing is
     drawn, whatever `noPlot` says."""
-    s = getallsamples(MCMC, derived=derived)
-    lnLike, maxlnLike, best = _max_like(MCMC, s, lnLike)
-    if lnLike is None:
+    best = _Best.of(MCMC, getallsamples(MCMC, derived=derived), lnLike)
+    if best is None:
         return None
-    maxLikeParams, maxLProb, maxLchi2 = best
-    print("chi2 at max = %f" % maxLchi2)
-    print('Max ln likelihood %f at parameters:' % maxlnLike)
-    assert abs(1. - maxLProb / maxlnLike) < 0.01, \
-        "different likelihood calculations differ: %f != %f" % (maxLProb, maxlnLike)
-    print(maxLikeParams)
-    return (maxlnLike, maxLikeParams)
+    print("chi2 at max = %f" % best.chi2)
+    print('Max ln likelihood %f at parameters:' % best.lnlike)
+    best.check()
+    print(best.params)
+    return best.result()
 
 
 def stddev(arr):
