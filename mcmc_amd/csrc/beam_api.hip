@@ -1,6 +1,8 @@
 // C ABI of the BeamFit path (include/mi355mcmc.h, "BeamFit" block).
 #include <cmath>
+#include <cstdlib>
 #include <memory>
+#include <vector>
 
 #include "beam_kernels.hpp"
 #include "problems.hpp"
@@ -12,6 +14,10 @@ struct BeamProblem {
   int xy_per_map = 0, sig_kind = 0;
   BeamPriorBox box{};
   DevBuf<double> x, y, d, w, sig;
+  DevBuf<double> xyref;            // [1 or M][2] midpoint of the coordinates' bounding box (beam_fold)
+  DevBuf<double> mono;             // one shared grid: [5][mstride] its monomials (k_beam_chi2_cl)
+  int64_t mstride = 0;
+  double xr = 0.0, yr = 0.0, hx = 0.0, hy = 0.0;   // reference point and half extents of the shared grid
   DevBuf<double> theta_in, theta_pm, partial, lnl, tmp;
 };
 
@@ -77,11 +83,34 @@ int mi355_beam_load(mi355_ctx* c, int64_t M, int64_t npix, const double* x, cons
     const double s2 = sig[i] * sig[i];                 // GaussianData.py:19
     w[i] = 1.0 / s2;
   }
+  // reference point of every coordinate set: the midpoint of its finite extent
+  const size_t nref = xy_per_map ? static_cast<size_t>(M) : 1;
+  std::vector<double> ref(2 * nref, 0.0);
+  for (size_t r = 0; r < nref; ++r)
+    for (int ax = 0; ax < 2; ++ax) {
+      const double* v = (ax ? y : x) + r * static_cast<size_t>(npix);
+      double lo = INFINITY, hi = -INFINITY;
+      for (int64_t i = 0; i < npix; ++i)
+        if (std::isfinite(v[i])) { lo = std::fmin(lo, v[i]); hi = std::fmax(hi, v[i]); }
+      if (lo <= hi) ref[2 * r + ax] = lo + 0.5 * (hi - lo);
+      if (lo <= hi && r == 0) (ax ? p->hy : p->hx) = 0.5 * (hi - lo);
+    }
+  if (p->xyref.alloc(ref.size())) return -2;
+  MI355_HIP(hipMemcpyAsync(p->xyref.p, ref.data(), ref.size() * 8, hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipMemcpyAsync(p->x.p, x, nxy * 8, hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipMemcpyAsync(p->y.p, y, nxy * 8, hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipMemcpyAsync(p->d.p, d, nd * 8, hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipMemcpyAsync(p->w.p, w.data(), ns * 8, hipMemcpyHostToDevice, c->stream));
   MI355_HIP(hipMemcpyAsync(p->sig.p, sig, ns * 8, hipMemcpyHostToDevice, c->stream));
+  if (!xy_per_map) {
+    p->mstride = (npix + 15) & ~static_cast<int64_t>(15);
+    p->xr = ref[0];
+    p->yr = ref[1];
+    if (p->mono.alloc(static_cast<size_t>(5 * p->mstride))) return -2;
+    hipLaunchKernelGGL(k_beam_mono, dim3(static_cast<unsigned>(ceil_div64(p->mstride, 256))), dim3(256), 0, c->stream,
+                       npix, p->mstride, p->x.p, p->y.p, p->xr, p->yr, p->mono.p);
+    MI355_HIP(hipGetLastError());
+  }
   MI355_HIP(hipStreamSynchronize(c->stream));
   beam_destroy(c->beam);
   c->beam = p.release();
@@ -99,6 +128,53 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
   MI355_REQUIRE(C > 0, "C must be positive");
   MI355_HIP(hipSetDevice(c->device));
   const int64_t n = nm * C;
+  // Many maps on one shared grid with (nearly) full groups of 16 chains: the quadratic form on the matrix
+  // cores (k_beam_chi2_mf); otherwise a lane per pixel and eight chains per block (k_beam_chi2: one map
+  // and one chain is the reference's own use).  MI355_BEAM_MF: 0 never, 1 wherever the grid is shared.
+  // (A value differs between the two kernels in the last bits - 1e-13 relative, summation order - so a
+  // job split into launches of very different sizes is not bit-for-bit the job in one launch.)
+  static const int mf_mode = [] { const char* e = getenv("MI355_BEAM_MF"); return e ? atoi(e) : -1; }();
+  const int ngrp16 = (C + 15) / 16;
+  if (!p->xy_per_map && mf_mode != 0 && (mf_mode == 1 || (n >= 1024 && C * 4 >= ngrp16 * 16 * 3))) {
+    const int64_t nunit = nm * ngrp16;
+    // pixel runs per unit: about 8192 waves in all (the time is flat from 2048 to 16 384 on C5), runs
+    // of at least 256 pixels
+    int64_t W = std::max<int64_t>(1, std::min<int64_t>(8192 / nunit, ceil_div64(p->npix, 256)));
+    const int64_t run = ceil_div64(ceil_div64(p->npix, W), 16) * 16;
+    W = ceil_div64(p->npix, run);
+    if (p->partial.alloc(static_cast<size_t>(n) * W)) return -2;
+    BeamMfArgs b{};
+    b.mono = p->mono.p;
+    b.mstride = p->mstride;
+    b.x = p->x.p;
+    b.y = p->y.p;
+    b.d = p->d.p;
+    b.w = p->w.p;
+    b.w_kind = p->sig_kind;
+    b.npix = p->npix;
+    b.m0 = m0;
+    b.C = C;
+    b.ngrp = ngrp16;
+    b.n = n;
+    b.nunit = nunit;
+    b.theta = theta_dev;
+    b.xr = p->xr;
+    b.yr = p->yr;
+    b.hx = p->hx;
+    b.hy = p->hy;
+    b.W = static_cast<int>(W);
+    b.run = run;
+    b.partial = p->partial.p;
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k_beam_chi2_mf, dim3(static_cast<unsigned>(ceil_div64(nunit * W, 4))), dim3(256), 0, c->stream, b);
+    MI355_HIP(hipGetLastError());
+    if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+    if (!c->capturing) c->ev_valid = true;
+    hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
+                       c->stream, n, static_cast<int>(W), p->partial.p, lnL_dev);
+    MI355_HIP(hipGetLastError());
+    return 0;
+  }
   const int ngrp = (C + kBeamCH - 1) / kBeamCH;
   // pixels per block: enough blocks to fill 256 CUs several times over, at least 512 pixels each
   int64_t want = ceil_div64(4096, nm * ngrp);
@@ -110,6 +186,7 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
   a.x = p->x.p;
   a.y = p->y.p;
   a.xy_per_map = p->xy_per_map;
+  a.xyref = p->xyref.p;
   a.d = p->d.p;
   a.w = p->w.p;
   a.w_kind = p->sig_kind;

@@ -15,12 +15,12 @@
 #include "beam_device.hpp"
 #include "common.hpp"
 #include "fastmath.hpp"
+#include <type_traits>
 
 namespace mi355 {
 
 constexpr int kBeamCH = 8;       // chains per register group
 constexpr int kBeamNC = 12;      // constants per chain in LDS
-constexpr int kBeamNF = 9;       // folded constants of the fast pixel loop
 
 // Per-chain constants of the model from PACKAGED parameters.
 //  k[0..1] centre, k[2..4] Cxx, Cyy, Cxy, k[5] amplitude, k[6] offset, k[7] plane factor
@@ -64,53 +64,63 @@ __device__ __forceinline__ double beam_model_at(const double* k, double x, doubl
   return k[5] * v;
 }
 
-// Folded constants for the pixel loop: the factor -1/2 of the exponent goes into C^-1 and the
-// plane factor into its direction cosines, so that a pixel costs 5 FMA-class operations for the
-// exponent, 3 for offset + plane and 1 for the residual (the reference's operation order, kept in
-// beam_model_at, costs 22).  The reassociation moves a model value by a few ulp, far inside the
-// 1e-12 budget of lnL (tests/test_beam_gpu.py).
-// The exponent is produced directly in base 2 (the folded C^-1 carries log2 e), so the
-// exponential needs no argument scaling: the table-driven 2^y of fastmath.hpp (exp2_tab_n), the
-// 8 chains of a pixel interleaved.
-//  f[0..1] centre, f[2] -Cxx/2 log2e, f[3] -Cyy/2 log2e, f[4] -Cxy log2e, f[5] offset,
-//  f[6..7] plane gradient, f[8] amplitude
-__device__ __forceinline__ void beam_fold(const double* k, double* f) {
-  f[0] = k[0];
-  f[1] = k[1];
-  f[2] = -0.5 * k[2] * kLog2e;
-  f[3] = -0.5 * k[3] * kLog2e;
-  f[4] = -k[4] * kLog2e;
-  f[5] = k[6];
+// Folded constants for the pixel loop.  The exponent -q/2 of the reference (BeamModel.py:290) is a
+// quadratic in the pixel's coordinates; written out around a reference point (xr, yr) of the MAP - not
+// of the chain - its monomials xs^2, ys^2, xs ys (xs = x - xr) are computed once per pixel for all the
+// chains of the block, and a chain's exponent is five FMAs on them, in base 2 (the folded C^-1 carries
+// -log2(e)/2, so the table-driven 2^y of fastmath.hpp needs no argument scaling).  Amplitude, offset
+// and plane fold into one linear form:  r = (d - L(xs, ys)) - amp 2^arg.  20 VALU instructions per
+// (pixel, chain) without a plane (mu = 1: what the reference's own runs keep fixed,
+// ProcessBeamData.py:220-221), 22 with one; the reference's operation order, kept in beam_model_at, costs
+// 46 FLOP, and the form before this one (differences per chain, exponent from dx, dy) cost 25
+// instructions.  The expansion around the map's midpoint costs precision where |xs| is many beam widths:
+// the monomial terms reach (extent / sigma)^2 and cancel to the exponent near the chain's centre - an
+// absolute error of that size times 2^-53 in the exponent, a few 1e-14 relative in the model value for
+// maps up to ~20 widths across, inside the 1e-12 budget of lnL (tests/test_beam_gpu.py, tests/
+// test_full_size_gpu.py).
+//  f[0..5] the quadratic's coefficients of (xs^2, ys^2, xs ys, xs, ys, 1), f[6] amplitude,
+//  f[7..9] L's coefficients of (1, xs, ys)
+constexpr int kBeamNF = 10;      // folded constants of the fast pixel loop
+__device__ __forceinline__ void beam_fold(const double* k, double xr, double yr, double* f) {
+  const double a = -0.5 * k[2] * kLog2e, b = -0.5 * k[3] * kLog2e, c = -k[4] * kLog2e;
+  const double ox = k[0] - xr, oy = k[1] - yr;             // the chain's centre from the reference point
+  f[0] = a;
+  f[1] = b;
+  f[2] = c;
+  f[3] = -(2.0 * a * ox + c * oy);
+  f[4] = -(2.0 * b * oy + c * ox);
+  f[5] = fma(a * ox, ox, fma(b * oy, oy, (c * ox) * oy));
+  f[6] = k[5];
   const bool plane = k[10] != 0.0;
-  f[6] = plane ? k[7] * k[8] : 0.0;
-  f[7] = plane ? k[7] * k[9] : 0.0;
-  f[8] = k[5];
+  const double px = plane ? k[7] * k[8] : 0.0, py = plane ? k[7] * k[9] : 0.0;
+  f[7] = k[5] * (k[6] - (px * ox + py * oy));
+  f[8] = k[5] * px;
+  f[9] = k[5] * py;
 }
 
-template <bool WPIX>
+template <bool WPIX, bool PLANE>
 __device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], const double* e2t,
-                                                double x, double y, double dv, double w,
+                                                double xs, double ys, double dv, double w,
                                                 double* acc) {
   constexpr int G = 4;                                     // chains interleaved at a time
+  const double xx = xs * xs, yy = ys * ys, xy = xs * ys;
 #pragma unroll
   for (int c0 = 0; c0 < kBeamCH; c0 += G) {
-    double dx[G], dy[G], arg[G], g[G];
+    double arg[G], g[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int c = c0 + i;
-      dx[i] = x - f[c][0];
-      dy[i] = y - f[c][1];
-      const double u = fma(f[c][4], dy[i], f[c][2] * dx[i]);
-      // the exponent of a positive-definite form is <= 0; the clamp keeps 2^arg a normal number
-      // (exp2_tab_n adds the power of two to the exponent field)
-      arg[i] = fmax(fma(dx[i], u, (f[c][3] * dy[i]) * dy[i]), -1000.0);
+      const double lin = fma(f[c][3], xs, fma(f[c][4], ys, f[c][5]));
+      // the exponent of a positive-definite form is <= 0 up to rounding; the clamp keeps 2^arg a
+      // normal number (exp2_tab_n adds the power of two to the exponent field)
+      arg[i] = fmax(fma(f[c][0], xx, fma(f[c][1], yy, fma(f[c][2], xy, lin))), -1000.0);
     }
     exp2_tab_n<G>(arg, e2t, g);
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int c = c0 + i;
-      const double v = fma(dx[i], f[c][6], fma(dy[i], f[c][7], g[i] + f[c][5]));
-      const double r = fma(-f[c][8], v, dv);
+      const double t = PLANE ? dv - fma(f[c][8], xs, fma(f[c][9], ys, f[c][7])) : dv - f[c][7];
+      const double r = fma(-f[c][6], g[i], t);
       acc[c] = WPIX ? fma(r * w, r, acc[c]) : fma(r, r, acc[c]);
     }
   }
@@ -128,12 +138,13 @@ struct BeamArgs {
   int C;                  // chains per map
   int64_t n;              // nm * C parameter vectors
   const double* theta;    // [9][n] parameter-major, vector e = (m - m0)*C + c
+  const double* xyref;    // [1][2] or [M][2]: the reference point of every map's coordinates (beam_fold)
   int chunk;              // pixels per block (multiple of 256)
   int nchunk;
   double* partial;        // [n][nchunk]
 };
 
-__global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
+__global__ __launch_bounds__(256, 2) void k_beam_chi2(BeamArgs a) {
   __shared__ double kc[kBeamCH][kBeamNC];
   __shared__ double fc[kBeamCH][kBeamNF];
   __shared__ double red[4][kBeamCH];
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
   const int grp = blockIdx.z;                          // chain group
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
+  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 2], yr = a.xyref[(a.xy_per_map ? m : 0) * 2 + 1];
   if (tid < kBeamCH) {
     double th[kBeamP];
     double k[kBeamNC];
@@ -160,13 +172,16 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
 #pragma unroll
     for (int i = 0; i < kBeamNC; ++i) kc[tid][i] = k[i];
     double f[kBeamNF];
-    beam_fold(k, f);
+    beam_fold(k, xr, yr, f);
 #pragma unroll
     for (int i = 0; i < kBeamNF; ++i) fc[tid][i] = f[i];
   }
   __syncthreads();
-  bool irregular = false;
-  for (int c = 0; c < nch; ++c) irregular = irregular || kc[c][11] != 0.0;
+  bool irregular = false, plane = false;
+  for (int c = 0; c < nch; ++c) {
+    irregular = irregular || kc[c][11] != 0.0;
+    plane = plane || kc[c][10] != 0.0;
+  }
 
   const double* xs = a.x + (a.xy_per_map ? m * a.npix : 0);
   const double* ys = a.y + (a.xy_per_map ? m * a.npix : 0);
@@ -178,14 +193,24 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
 #pragma unroll
   for (int c = 0; c < kBeamCH; ++c) acc[c] = 0.0;
   const double w_shared = (a.w_kind == 2) ? 0.0 : ws[0];
-  if (!irregular && a.w_kind == 2) {
-    for (int64_t p = p0 + tid; p < p1; p += 256)
-      beam_pixel_fast<true>(fc, e2t, xs[p], ys[p], ds[p], ws[p], acc);   // GaussianData.py:47
-  } else if (!irregular) {
-    for (int64_t p = p0 + tid; p < p1; p += 256)                    // one weight: taken out of the sum
-      beam_pixel_fast<false>(fc, e2t, xs[p], ys[p], ds[p], 0.0, acc);
+  if (!irregular) {
+    // four instantiations of one loop: per-pixel weights or one weight taken out of the sum
+    // (GaussianData.py:47), with or without a plane in any chain of the block
+    // (fetching a pixel an iteration ahead was measured and is no faster: two waves per SIMD cover
+    // the loads already)
+    auto pixels = [&](auto wpix, auto pl) {
+      constexpr bool WP = decltype(wpix)::value;
+      for (int64_t p = p0 + tid; p < p1; p += 256)
+        beam_pixel_fast<WP, decltype(pl)::value>(fc, e2t, xs[p] - xr, ys[p] - yr, ds[p], WP ? ws[p] : 0.0, acc);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (a.w_kind == 2) { if (plane) pixels(T{}, T{}); else pixels(T{}, F{}); }
+    else               { if (plane) pixels(F{}, T{}); else pixels(F{}, F{}); }
+    if (a.w_kind != 2) {
 #pragma unroll
-    for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
+      for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
+    }
   } else {
     for (int64_t p = p0 + tid; p < p1; p += 256) {
       const double x = xs[p], y = ys[p], dv = ds[p];
@@ -210,6 +235,223 @@ __global__ __launch_bounds__(256) void k_beam_chi2(BeamArgs a) {
     const int64_t e = ml * a.C + c0 + tid;
     a.partial[e * a.nchunk + blockIdx.x] = s;
   }
+}
+
+// ---- the quadratic form on the matrix cores ------------------------------------------------------
+// arg[chain][pixel] = sum_k coef_k[chain] mono_k[pixel] is a [chains x 4] . [4 x pixels] product per tile
+// of 16 chains of one map and 16 pixels: ONE v_mfma_f64_16x16x4_f64 with A = the chains' coefficients of
+// (xs^2, ys^2, xs ys, xs) - a lane's A entry never changes: lane l holds coefficient l / 16 of chain
+// l % 16 -, B = those monomials of the tile's pixels (filled in once per grid by k_beam_mono) and C = the
+// constant terms.  The VALU is left with the ys term, the exponential and the residual: 16 instructions
+// per (pixel, chain) against 21 in k_beam_chi2, and none of its 128 registers of chain constants.  The result tile gives lane l the chains l / 16 + 4 v, v = 0 .. 3, at pixel
+// l % 16: a tile costs a lane three 8-byte loads (its monomial, ys and the datum of its pixel; a lane per
+// (chain, four pixels) would fetch 72 bytes and be bound by the vector memory pipe), all through one
+// scalar base that the scalar unit moves from tile to tile.  The four chains' constants come from their
+// owner lanes by shuffles before the loop.
+// One wave = 16 chains of one map (chains beyond C idle: the host picks this kernel for C >= 12 of 16)
+// over a run of pixels; a lane's four sums are added over the 16 pixel columns at the end.  Exponents are
+// not clamped here: chains whose form can exceed 2^39 on the grid (exp2_tab_n's range) count as irregular,
+// and a wave with such a chain runs the exact model.
+typedef double beam_d4 __attribute__((ext_vector_type(4)));
+
+struct BeamMfArgs {
+  const double* mono;     // [5][mstride]: xs, ys, xs^2, ys^2, xs ys; zeros beyond npix (mstride: multiple of 16)
+  int64_t mstride;
+  const double* x;
+  const double* y;
+  const double* d;
+  const double* w;
+  int w_kind;
+  int64_t npix;
+  int64_t m0;
+  int C;
+  int ngrp;               // groups of 16 chains per map
+  int64_t n;              // nm * C
+  int64_t nunit;          // nm * ngrp
+  const double* theta;    // [9][n]
+  double xr, yr;
+  double hx, hy;          // half extents of the grid around (xr, yr)
+  int W;                  // waves (pixel runs) per unit
+  int64_t run;            // pixels per run (multiple of 16)
+  double* partial;        // [n][W]
+};
+
+// a double at (wave-uniform base) + (the lane's 32-bit byte offset): a global load with a scalar base
+__device__ __forceinline__ double beam_ldu(const double* base, uint32_t off) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off);
+}
+
+struct BeamMfChains {     // constants of the lane's four chains l / 16 + 4 v
+  double e[4];            // coefficient of ys
+  double amp[4];
+  double p0[4], px[4], py[4];   // the linear form L
+};
+
+// Measured on C5 (2000 maps x 16 chains x 256^2 pixels, tools/prof_beam.sh, profiles/r3_beam_summary.txt):
+// 1.63 ms against k_beam_chi2's 2.09 (2.26 before its own monomial form).  The time does not move with
+// occupancy (2 to 16 waves per SIMD: 1.71 - 1.62 ms), with the table reads made conflict-free, or with
+// the loads fetched further ahead: the FP64 matrix and vector instructions share the SIMD's FP64
+// multipliers, and the clock under this instruction mix is 2.03 GHz (GRBM_GUI_ACTIVE), not 2.4 - the
+// kernel runs at about 0.8 of the FP64 issue rate the chip sustains.
+constexpr int kBeamMfU = 8;                 // tiles per loop iteration: their loads are issued together
+
+// U tiles of 16 pixels from pixel p on (mono_p, d_p, w_p point at it)
+template <bool WPIX, bool PLANE, int U>
+__device__ __forceinline__ void beam_tiles_mf(const BeamMfChains& ch, const beam_d4& cinit, double acoef,
+                                              const double* e2t, const double* mono_p, uint32_t ob,
+                                              uint32_t oy, uint32_t ox, const double* d_p, const double* w_p,
+                                              uint32_t od, double* acc) {
+  double bv[U], ys[U], dv[U], xs[U], wv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bv[u] = beam_ldu(mono_p + 16 * u, ob);
+    ys[u] = beam_ldu(mono_p + 16 * u, oy);
+    dv[u] = beam_ldu(d_p + 16 * u, od);
+    xs[u] = PLANE ? beam_ldu(mono_p + 16 * u, ox) : 0.0;
+    wv[u] = WPIX ? beam_ldu(w_p + 16 * u, od) : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const beam_d4 q = __builtin_amdgcn_mfma_f64_16x16x4f64(acoef, bv[u], cinit, 0, 0, 0);
+    double arg[4], g[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) arg[v] = fma(ch.e[v], ys[u], q[v]);
+    exp2_tab_n<4>(arg, e2t, g);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double t = PLANE ? dv[u] - fma(ch.px[v], xs[u], fma(ch.py[v], ys[u], ch.p0[v])) : dv[u] - ch.p0[v];
+      const double r = fma(-ch.amp[v], g[v], t);
+      acc[v] = WPIX ? fma(r * wv[u], r, acc[v]) : fma(r, r, acc[v]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void k_beam_chi2_mf(BeamMfArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);             // (scalar: so is everything derived from it)
+  const double* e2t = stage_exp2_table();
+  __syncthreads();
+  const int64_t wid = static_cast<int64_t>(blockIdx.x) * 4 + wv;       // wave-uniform
+  if (wid >= a.nunit * a.W) return;
+  const int64_t unit = wid / a.W;
+  const int run_i = static_cast<int>(wid - unit * a.W);
+  const int64_t ml = unit / a.ngrp;
+  const int cg = static_cast<int>(unit - ml * a.ngrp);
+  const int64_t m = a.m0 + ml;
+  const int j16 = lane & 15, kq = lane >> 4;
+  // the lane's OWN chain cg 16 + j16: its constants are computed here and handed out below
+  const int c_own = cg * 16 + j16;
+  const int64_t e_own = ml * a.C + (c_own < a.C ? c_own : a.C - 1);
+  double k[kBeamNC], f[kBeamNF];
+  {
+    double th[kBeamP];
+#pragma unroll
+    for (int i = 0; i < kBeamP; ++i) th[i] = a.theta[i * a.n + e_own];
+    beam_package(th);
+    beam_consts(th, k);
+    beam_fold(k, a.xr, a.yr, f);
+  }
+  // the form's largest exponent on the grid against the table kernel's range
+  const double big = fabs(f[0]) * a.hx * a.hx + fabs(f[1]) * a.hy * a.hy + fabs(f[2]) * a.hx * a.hy +
+                     fabs(f[3]) * a.hx + fabs(f[4]) * a.hy + fabs(f[5]);
+  const bool irregular = k[11] != 0.0 || !(big < 0x1p39);
+  const bool wave_irregular = __builtin_amdgcn_ballot_w64(irregular) != 0;
+  const bool wave_plane = __builtin_amdgcn_ballot_w64(k[10] != 0.0) != 0;
+  const double* dl = a.d + m * a.npix;                                 // wave-uniform
+  const double* wl = a.w + (a.w_kind == 2 ? m * a.npix : (a.w_kind == 1 ? m : 0));
+  const int64_t p0 = run_i * a.run;
+  const int64_t p1 = min(p0 + a.run, a.npix);
+  if (wave_irregular) {
+    // the exact model, a lane per (own chain, every fourth pixel); summed over the four row groups
+    double acc = 0.0;
+    for (int64_t p = p0 + kq; p < p1; p += 4) {
+      const double w = (a.w_kind == 2) ? wl[p] : wl[0];
+      const double r = dl[p] - beam_model_at<true>(k, a.x[p], a.y[p]);
+      acc += (r * w) * r;
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (c_own < a.C && kq == 0) a.partial[e_own * a.W + run_i] = acc;
+    return;
+  }
+  // A[i = chain j16][k = kq]: coefficient of xs^2, ys^2, xs ys, xs; the lane's chains kq + 4 v from their owners
+  const double acoef = (kq == 0) ? f[0] : (kq == 1) ? f[1] : (kq == 2) ? f[2] : f[3];
+  BeamMfChains ch;
+  beam_d4 cinit;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int src = kq + 4 * v;                            // lanes 0 .. 15 own chains 0 .. 15 of the group
+    cinit[v] = __shfl(f[5], src);
+    ch.e[v] = __shfl(f[4], src);
+    ch.amp[v] = __shfl(f[6], src);
+    ch.p0[v] = __shfl(f[7], src);
+    ch.px[v] = __shfl(f[8], src);
+    ch.py[v] = __shfl(f[9], src);
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const uint32_t ob = static_cast<uint32_t>((((kq == 3) ? 0 : (kq + 2)) * a.mstride + j16) * 8);   // rows xs^2, ys^2, xs ys, xs
+  const uint32_t oy = static_cast<uint32_t>((a.mstride + j16) * 8);
+  const uint32_t ox = static_cast<uint32_t>(j16 * 8);
+  auto pixels = [&](auto wpix, auto pl) {
+    constexpr bool WP = decltype(wpix)::value;
+    constexpr bool PL = decltype(pl)::value;
+    int64_t p = p0;
+    for (; p + 16 * kBeamMfU <= p1; p += 16 * kBeamMfU)
+      beam_tiles_mf<WP, PL, kBeamMfU>(ch, cinit, acoef, e2t, a.mono + p, ob, oy, ox, dl + p, wl + p, /* od = */ ox, acc);
+    for (; p + 16 <= p1; p += 16)
+      beam_tiles_mf<WP, PL, 1>(ch, cinit, acoef, e2t, a.mono + p, ob, oy, ox, dl + p, wl + p, /* od = */ ox, acc);
+    // the grid's last pixels (fewer than 16): pixel column j16 while there is one, the form by FMAs
+    // (the four chains' coefficients fetched by every lane, before the lanes without a pixel drop out)
+    if (p < p1) {
+      double cq[4][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cq[v][i] = __shfl(f[i], kq + 4 * v);
+      if (p + j16 < p1) {
+        const int64_t pp = p + j16;
+        const double xs = a.mono[pp], ys = a.mono[a.mstride + pp];
+        const double xx = a.mono[2 * a.mstride + pp], yy = a.mono[3 * a.mstride + pp], xy = a.mono[4 * a.mstride + pp];
+        const double dv = dl[pp];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double lin = fma(cq[v][3], xs, fma(ch.e[v], ys, cinit[v]));
+          const double g = exp2_tab(fma(cq[v][0], xx, fma(cq[v][1], yy, fma(cq[v][2], xy, lin))), e2t);
+          const double t = PL ? dv - fma(ch.px[v], xs, fma(ch.py[v], ys, ch.p0[v])) : dv - ch.p0[v];
+          const double r = fma(-ch.amp[v], g, t);
+          acc[v] = WP ? fma(r * wl[pp], r, acc[v]) : fma(r, r, acc[v]);
+        }
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  if (a.w_kind == 2) { if (wave_plane) pixels(T{}, T{}); else pixels(T{}, F{}); }
+  else               { if (wave_plane) pixels(F{}, T{}); else pixels(F{}, F{}); }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double sum = acc[v];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    sum += __shfl_xor(sum, 8);
+    if (a.w_kind != 2) sum *= wl[0];
+    const int c = cg * 16 + kq + 4 * v;
+    if (j16 == 0 && c < a.C) a.partial[(ml * a.C + c) * a.W + run_i] = sum;
+  }
+}
+
+// the monomials of a coordinate grid around its reference point, [5][mstride], zeros beyond npix
+__global__ void k_beam_mono(int64_t npix, int64_t mstride, const double* __restrict__ x,
+                            const double* __restrict__ y, double xr, double yr, double* __restrict__ mono) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= mstride) return;
+  const double xs = p < npix ? x[p] - xr : 0.0, ys = p < npix ? y[p] - yr : 0.0;
+  mono[p] = xs;
+  mono[mstride + p] = ys;
+  mono[2 * mstride + p] = xs * xs;
+  mono[3 * mstride + p] = ys * ys;
+  mono[4 * mstride + p] = xs * ys;
 }
 
 // lnL = -chi2/2 with the chunk sums added in ascending order

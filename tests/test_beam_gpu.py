@@ -82,6 +82,38 @@ def test_beam_many_maps_against_oracle():
         close(got[m], ref)
 
 
+@pytest.mark.parametrize("n,C,per_pixel_sigma", [(48, 16, False), (47, 13, False), (47, 16, True)])
+def test_beam_many_maps_on_the_matrix_cores(n, C, per_pixel_sigma):
+    """The kernel that large jobs on one shared grid take (k_beam_chi2_mf: >= 1024 (map, chain) pairs,
+    groups of 16 chains at least three quarters full): against the oracle on a few maps, and against
+    the lane-per-pixel kernel (what a launch of few pairs takes) on all of them.  47 x 47 pixels leave
+    a last tile of one pixel; C = 13 leaves three idle rows per tile; chains with and without a plane
+    share waves; one chain has a non-finite width (its wave runs the exact model)."""
+    from oracle import refbeam as RB
+    from mcmc_amd import Engine
+    M = 96
+    x, y, d, noise, truth, prior = RB.synth_beam_maps(M, n=n, seed=21)
+    rng = np.random.default_rng(9)
+    th = truth[:, None, :] * (1 + 0.03 * rng.standard_normal((M, C, 9)))
+    th[:, 0::2, 7] = 1.0                                              # no plane (mu = 1: the integer 0)
+    th[:, 1::2, 7] = rng.uniform(0.8, 1.0, (M, C // 2))               # every other chain: a plane
+    th[:, 0, :] = truth
+    th[40, 5, 2] = np.inf                                             # one irregular wave: the exact model
+    th[41, 4, 7] = 1.02                                               # mu > 1: NaN, as the reference
+    sig = noise * (1 + 0.5 * rng.random((M, n * n))) if per_pixel_sigma else noise
+    with Engine() as eng:
+        eng.beam_load(x, y, d, sig, center_min=prior.center_min, center_max=prior.center_max,
+                      sig_min=prior.sig_min, sig_max=prior.sig_max)
+        got = eng.beam_lnlike(th)                                     # 96 C >= 1024 pairs
+        small = np.concatenate([eng.beam_lnlike(th[m0:m0 + 8], m0=m0) for m0 in range(0, M, 8)])
+    assert not np.isfinite(got[40, 5]) and np.isnan(got[41, 4]) and np.isfinite(got).sum() == got.size - 2
+    close(got, small, rtol=1e-12)
+    for m in (0, 40, 95):
+        bm = RB.BeamMap(x, y, d[m], sig[m] if per_pixel_sigma else noise)
+        ref = [RB.beam_lnlike(RB.beam_package(th[m, c]), bm) for c in range(C)]
+        close(got[m], ref)
+
+
 def test_beam_errors():
     from mcmc_amd import Engine, Mi355Error
     with Engine() as eng:
