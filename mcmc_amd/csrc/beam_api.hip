@@ -35,6 +35,19 @@ static int beam_ready(mi355_ctx* c, const char* who) {
   return 0;
 }
 
+// k_beam_chi2's pixel chunks: enough blocks to fill 256 CUs several times over, at least 512 pixels each
+static void beam_px_plan(int64_t nm, int ngrp, int64_t npix, int64_t* nchunk, int64_t* chunk) {
+  const int64_t want = ceil_div64(4096, nm * ngrp);
+  int64_t nc = std::max<int64_t>(1, std::min<int64_t>(want, ceil_div64(npix, 512)));
+  *chunk = ceil_div64(ceil_div64(npix, nc), 256) * 256;
+  *nchunk = ceil_div64(npix, *chunk);
+}
+
+static int beam_mf_mode() {
+  static const int m = [] { const char* e = getenv("MI355_BEAM_MF"); return e ? atoi(e) : -1; }();
+  return m;
+}
+
 // [n][9] -> [9][n]
 __global__ void k_beam_to_pm(int64_t n, const double* __restrict__ in, double* __restrict__ out) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -119,9 +132,28 @@ int mi355_beam_load(mi355_ctx* c, int64_t M, int64_t npix, const double* x, cons
 
 int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
                                 const double* theta_dev, double* lnL_dev) {
+  MI355_REQUIRE(lnL_dev, "mi355_beam_lnlike: null buffer");
+  const double* partial = nullptr;
+  int nchunk = 0;
+  const int rc = beam_chi2_partials_async(c, m0, nm, C, theta_dev, &partial, &nchunk);
+  if (rc) return rc;
+  const int64_t n = nm * C;
+  hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
+                     c->stream, n, nchunk, partial, lnL_dev);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+namespace mi355 {
+// The chi-square kernels alone: partial[n][nchunk] (lnL = -1/2 of a row's sum in ascending order:
+// k_beam_finish, or the accept step of the Metropolis-Hastings engine itself)
+int beam_chi2_partials_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta_dev,
+                             const double** partial_out, int* nchunk_out) {
   if (beam_ready(c, "mi355_beam_lnlike")) return -1;
   BeamProblem* p = c->beam;
-  MI355_REQUIRE(theta_dev && lnL_dev, "mi355_beam_lnlike: null buffer");
+  MI355_REQUIRE(theta_dev, "mi355_beam_lnlike: null buffer");
   MI355_REQUIRE(m0 >= 0 && nm > 0 && m0 + nm <= p->M, "map range [%lld,%lld) outside [0,%lld)",
                 static_cast<long long>(m0), static_cast<long long>(m0 + nm),
                 static_cast<long long>(p->M));
@@ -133,7 +165,7 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
   // and one chain is the reference's own use).  MI355_BEAM_MF: 0 never, 1 wherever the grid is shared.
   // (A value differs between the two kernels in the last bits - 1e-13 relative, summation order - so a
   // job split into launches of very different sizes is not bit-for-bit the job in one launch.)
-  static const int mf_mode = [] { const char* e = getenv("MI355_BEAM_MF"); return e ? atoi(e) : -1; }();
+  const int mf_mode = beam_mf_mode();
   const int ngrp16 = (C + 15) / 16;
   if (!p->xy_per_map && mf_mode != 0 && (mf_mode == 1 || (n >= 1024 && C * 4 >= ngrp16 * 16 * 3))) {
     const int64_t nunit = nm * ngrp16;
@@ -170,17 +202,13 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
     MI355_HIP(hipGetLastError());
     if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
     if (!c->capturing) c->ev_valid = true;
-    hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
-                       c->stream, n, static_cast<int>(W), p->partial.p, lnL_dev);
-    MI355_HIP(hipGetLastError());
+    *partial_out = p->partial.p;
+    *nchunk_out = static_cast<int>(W);
     return 0;
   }
   const int ngrp = (C + kBeamCH - 1) / kBeamCH;
-  // pixels per block: enough blocks to fill 256 CUs several times over, at least 512 pixels each
-  int64_t want = ceil_div64(4096, nm * ngrp);
-  int64_t nchunk = std::max<int64_t>(1, std::min<int64_t>(want, ceil_div64(p->npix, 512)));
-  int64_t chunk = ceil_div64(ceil_div64(p->npix, nchunk), 256) * 256;
-  nchunk = ceil_div64(p->npix, chunk);
+  int64_t nchunk, chunk;
+  beam_px_plan(nm, ngrp, p->npix, &nchunk, &chunk);
   if (p->partial.alloc(static_cast<size_t>(n) * nchunk)) return -2;
   BeamArgs a{};
   a.x = p->x.p;
@@ -211,11 +239,13 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
   }
   if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
   if (!c->capturing) c->ev_valid = true;
-  hipLaunchKernelGGL(k_beam_finish, dim3(static_cast<unsigned>(ceil_div64(n, 256))), dim3(256), 0,
-                     c->stream, n, static_cast<int>(nchunk), p->partial.p, lnL_dev);
-  MI355_HIP(hipGetLastError());
+  *partial_out = p->partial.p;
+  *nchunk_out = static_cast<int>(nchunk);
   return 0;
 }
+}  // namespace mi355
+
+extern "C" {
 
 int mi355_beam_lnlike(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta,
                       double* lnL) {

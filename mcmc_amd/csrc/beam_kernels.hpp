@@ -98,14 +98,16 @@ __device__ __forceinline__ void beam_fold(const double* k, double xr, double yr,
   f[9] = k[5] * py;
 }
 
-template <bool WPIX, bool PLANE>
+// NCH: chains of the block that exist (1 .. kBeamCH): a block of one chain - the reference's own use -
+// runs one chain's instructions, not eight; a chain's arithmetic does not depend on NCH
+template <bool WPIX, bool PLANE, int NCH>
 __device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], const double* e2t,
                                                 double xs, double ys, double dv, double w,
                                                 double* acc) {
-  constexpr int G = 4;                                     // chains interleaved at a time
+  constexpr int G = NCH < 4 ? NCH : 4;                     // chains interleaved at a time
   const double xx = xs * xs, yy = ys * ys, xy = xs * ys;
 #pragma unroll
-  for (int c0 = 0; c0 < kBeamCH; c0 += G) {
+  for (int c0 = 0; c0 < NCH; c0 += G) {
     double arg[G], g[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
@@ -144,69 +146,86 @@ struct BeamArgs {
   double* partial;        // [n][nchunk]
 };
 
-__global__ __launch_bounds__(256, 2) void k_beam_chi2(BeamArgs a) {
-  __shared__ double kc[kBeamCH][kBeamNC];
-  __shared__ double fc[kBeamCH][kBeamNF];
-  __shared__ double red[4][kBeamCH];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const double* e2t = stage_exp2_table();              // valid after the barrier below
-  const int64_t ml = blockIdx.y;                       // map within this call
+// LDS of a block of k_beam_chi2
+struct BeamBlockLds {
+  double kc[kBeamCH][kBeamNC];
+  double fc[kBeamCH][kBeamNF];
+  double red[4][kBeamCH];
+};
+
+// the constants of chain group `grp` of map `ml` (of this call) into LDS: threads 0 .. 7; the caller
+// puts a barrier behind it
+__device__ __forceinline__ void beam_group_consts(const BeamArgs& a, int64_t ml, int grp, BeamBlockLds& L) {
+  const int tid = threadIdx.x;
+  if (tid >= kBeamCH) return;
   const int64_t m = a.m0 + ml;
-  const int grp = blockIdx.z;                          // chain group
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
   const double xr = a.xyref[(a.xy_per_map ? m : 0) * 2], yr = a.xyref[(a.xy_per_map ? m : 0) * 2 + 1];
-  if (tid < kBeamCH) {
-    double th[kBeamP];
-    double k[kBeamNC];
-    if (tid < nch) {
-      const int64_t e = ml * a.C + c0 + tid;
+  double th[kBeamP];
+  double k[kBeamNC];
+  if (tid < nch) {
+    const int64_t e = ml * a.C + c0 + tid;
 #pragma unroll
-      for (int i = 0; i < kBeamP; ++i) th[i] = a.theta[i * a.n + e];
-      beam_package(th);
-      beam_consts(th, k);
-    } else {
+    for (int i = 0; i < kBeamP; ++i) th[i] = a.theta[i * a.n + e];
+    beam_package(th);
+    beam_consts(th, k);
+  } else {
 #pragma unroll
-      for (int i = 0; i < kBeamNC; ++i) k[i] = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < kBeamNC; ++i) kc[tid][i] = k[i];
-    double f[kBeamNF];
-    beam_fold(k, xr, yr, f);
-#pragma unroll
-    for (int i = 0; i < kBeamNF; ++i) fc[tid][i] = f[i];
+    for (int i = 0; i < kBeamNC; ++i) k[i] = 0.0;
   }
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kBeamNC; ++i) L.kc[tid][i] = k[i];
+  double f[kBeamNF];
+  beam_fold(k, xr, yr, f);
+#pragma unroll
+  for (int i = 0; i < kBeamNF; ++i) L.fc[tid][i] = f[i];
+}
+
+// pixel chunk `bx` of map `ml` for the chains of group `grp` (constants in LDS): every thread's partial
+// sums, the block's reduction, partial[e][bx].  Contains two barriers; every thread of the block calls it.
+__device__ __forceinline__ void beam_chunk(const BeamArgs& a, int bx, int64_t ml, int grp, BeamBlockLds& L,
+                                           const double* e2t) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m = a.m0 + ml;
+  const int c0 = grp * kBeamCH;
+  const int nch = min(kBeamCH, a.C - c0);
+  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 2], yr = a.xyref[(a.xy_per_map ? m : 0) * 2 + 1];
   bool irregular = false, plane = false;
   for (int c = 0; c < nch; ++c) {
-    irregular = irregular || kc[c][11] != 0.0;
-    plane = plane || kc[c][10] != 0.0;
+    irregular = irregular || L.kc[c][11] != 0.0;
+    plane = plane || L.kc[c][10] != 0.0;
   }
-
   const double* xs = a.x + (a.xy_per_map ? m * a.npix : 0);
   const double* ys = a.y + (a.xy_per_map ? m * a.npix : 0);
   const double* ds = a.d + m * a.npix;
   const double* ws = a.w + (a.w_kind == 2 ? m * a.npix : (a.w_kind == 1 ? m : 0));
-  const int64_t p0 = static_cast<int64_t>(blockIdx.x) * a.chunk;
+  const int64_t p0 = static_cast<int64_t>(bx) * a.chunk;
   const int64_t p1 = min(p0 + a.chunk, a.npix);
   double acc[kBeamCH];
 #pragma unroll
   for (int c = 0; c < kBeamCH; ++c) acc[c] = 0.0;
   const double w_shared = (a.w_kind == 2) ? 0.0 : ws[0];
   if (!irregular) {
-    // four instantiations of one loop: per-pixel weights or one weight taken out of the sum
-    // (GaussianData.py:47), with or without a plane in any chain of the block
+    // instantiations of one loop: per-pixel weights or one weight taken out of the sum
+    // (GaussianData.py:47), with or without a plane in any chain of the block, 1 / up to 4 / up to 8 chains
     // (fetching a pixel an iteration ahead was measured and is no faster: two waves per SIMD cover
     // the loads already)
-    auto pixels = [&](auto wpix, auto pl) {
+    auto pixels = [&](auto wpix, auto pl, auto nc) {
       constexpr bool WP = decltype(wpix)::value;
       for (int64_t p = p0 + tid; p < p1; p += 256)
-        beam_pixel_fast<WP, decltype(pl)::value>(fc, e2t, xs[p] - xr, ys[p] - yr, ds[p], WP ? ws[p] : 0.0, acc);
+        beam_pixel_fast<WP, decltype(pl)::value, decltype(nc)::value>(L.fc, e2t, xs[p] - xr, ys[p] - yr, ds[p],
+                                                                     WP ? ws[p] : 0.0, acc);
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (a.w_kind == 2) { if (plane) pixels(T{}, T{}); else pixels(T{}, F{}); }
-    else               { if (plane) pixels(F{}, T{}); else pixels(F{}, F{}); }
+    auto by_chains = [&](auto wpix, auto pl) {
+      if (nch == 1) pixels(wpix, pl, std::integral_constant<int, 1>{});
+      else if (nch <= 4) pixels(wpix, pl, std::integral_constant<int, 4>{});
+      else pixels(wpix, pl, std::integral_constant<int, kBeamCH>{});
+    };
+    if (a.w_kind == 2) { if (plane) by_chains(T{}, T{}); else by_chains(T{}, F{}); }
+    else               { if (plane) by_chains(F{}, T{}); else by_chains(F{}, F{}); }
     if (a.w_kind != 2) {
 #pragma unroll
       for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
@@ -217,24 +236,42 @@ __global__ __launch_bounds__(256, 2) void k_beam_chi2(BeamArgs a) {
       const double w = (a.w_kind == 2) ? ws[p] : w_shared;
 #pragma unroll
       for (int c = 0; c < kBeamCH; ++c) {
-        const double r = dv - beam_model_at<true>(kc[c], x, y);
+        const double r = dv - beam_model_at<true>(L.kc[c], x, y);
         acc[c] += (r * w) * r;
       }
     }
   }
 #pragma unroll
   for (int c = 0; c < kBeamCH; ++c) {
-    double v = acc[c];
+    if (c < nch) {                                         // (uniform: a block of one chain reduces one sum)
+      double v = acc[c];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) red[wv][c] = v;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) L.red[wv][c] = v;
+    }
   }
   __syncthreads();
   if (tid < nch) {
-    const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    const double s = ((L.red[0][tid] + L.red[1][tid]) + L.red[2][tid]) + L.red[3][tid];
     const int64_t e = ml * a.C + c0 + tid;
-    a.partial[e * a.nchunk + blockIdx.x] = s;
+    a.partial[e * a.nchunk + bx] = s;
   }
+  __syncthreads();                                         // (red is free again)
+}
+
+__global__ __launch_bounds__(256, 2) void k_beam_chi2(BeamArgs a) {
+  __shared__ BeamBlockLds L;
+  const double* e2t = stage_exp2_table();              // valid after the barrier below
+  beam_group_consts(a, blockIdx.y, blockIdx.z, L);
+  __syncthreads();
+  beam_chunk(a, blockIdx.x, blockIdx.y, blockIdx.z, L, e2t);
+}
+
+// lnL = -chi2/2 with the chunk sums added in ascending order
+__device__ __forceinline__ double beam_finish_one(int64_t e, int nchunk, const double* partial) {
+  double s = 0.0;
+  for (int j = 0; j < nchunk; ++j) s += partial[e * nchunk + j];
+  return -0.5 * s;                                                     // NormalizedBeamLikelihood.py:16
 }
 
 // ---- the quadratic form on the matrix cores ------------------------------------------------------
@@ -454,14 +491,11 @@ __global__ void k_beam_mono(int64_t npix, int64_t mstride, const double* __restr
   mono[4 * mstride + p] = xs * ys;
 }
 
-// lnL = -chi2/2 with the chunk sums added in ascending order
 __global__ void k_beam_finish(int64_t n, int nchunk, const double* __restrict__ partial,
                               double* __restrict__ lnl) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  double s = 0.0;
-  for (int j = 0; j < nchunk; ++j) s += partial[e * nchunk + j];
-  lnl[e] = -0.5 * s;                                                 // NormalizedBeamLikelihood.py:16
+  lnl[e] = beam_finish_one(e, nchunk, partial);
 }
 
 // prior and package of n flat vectors, host layout [n][9]

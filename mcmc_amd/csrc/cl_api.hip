@@ -436,7 +436,8 @@ static bool cl_mh_block_ok(const ClProblem* p, int P, int nblock, int npn) {
 
 int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn) {
   if (!c || !c->cl || !c->cl->binned) return 0;
-  if (cl_mhw_plan(c->cl, P, nblock, npn, int64_t{1} << 30).ok) return 1;   // the wave-per-16-chains kernel
+  // (the wave-per-16-chains kernel: its policy depends on the number of chains of the job)
+  if (cl_mhw_plan(c->cl, P, nblock, npn, c->N > 0 ? c->N : int64_t{1} << 30).ok) return 1;
   return cl_mh_block_ok(c->cl, P, nblock, npn) ? c->cl->mh_nw : 0;
 }
 

@@ -169,23 +169,43 @@ static int finish_start(mi355_ctx* c, GmhArgs& a, const char* who) {
   return check_flags(c, who);
 }
 
-// launch the kernels of one MH step on the context stream
-static int launch_step(mi355_ctx* c, const GmhArgs& a) {
-  GmhState* g = c->gmh;
-  const int cb = 1 << a.cb_shift;
-  const unsigned grid = static_cast<unsigned>(ceil_div64(c->N, cb));
-  const size_t lds = static_cast<size_t>(a.pb.P + 1) * cb * sizeof(double);
-  hipLaunchKernelGGL(k_gmh_propose, dim3(grid), dim3(256), lds, c->stream, a);
+// The launches of MH steps on the context stream.  A run is
+//   propose(0) | lnl, accept(0) + propose(1) | lnl, accept(1) + propose(2) | ... | lnl, accept(last):
+// the accept of a step and the proposal of the next share one launch (k_gmh_accept_propose), and the
+// beam chi-square leaves its chunk sums for the accept step to add up (no finish launch).
+static unsigned step_grid(mi355_ctx* c, const GmhArgs& a) {
+  return static_cast<unsigned>(ceil_div64(c->N, 1 << a.cb_shift));
+}
+static size_t step_lds(const GmhArgs& a) {
+  return static_cast<size_t>(a.pb.P + 1) * (1 << a.cb_shift) * sizeof(double);
+}
+static int launch_propose(mi355_ctx* c, const GmhArgs& a) {
+  hipLaunchKernelGGL(k_gmh_propose, dim3(step_grid(c, a)), dim3(256), step_lds(a), c->stream, a);
   MI355_HIP(hipGetLastError());
-  int rc = problem_lnlike(c, g->theta_new.p, g->lnl_new.p);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_gmh_accept, dim3(grid), dim3(256), lds, c->stream, a);
+  return 0;
+}
+// likelihood of the proposals in theta_new: into lnl_new, or (beam) as chunk sums the accept step reads
+static int launch_lnl(mi355_ctx* c, GmhArgs& a) {
+  GmhState* g = c->gmh;
+  a.lnl_partial = nullptr;
+  a.lnl_nchunk = 0;
+  if (g->pb.kind == GMH_BEAM)
+    return beam_chi2_partials_async(c, 0, c->mhS, c->C, g->theta_new.p, &a.lnl_partial, &a.lnl_nchunk);
+  return problem_lnlike(c, g->theta_new.p, g->lnl_new.p);
+}
+// accept of `a`'s step, and the proposal of the next (`next` non-null)
+static int launch_accept(mi355_ctx* c, const GmhArgs& a, const GmhArgs* next) {
+  if (next)
+    hipLaunchKernelGGL(k_gmh_accept_propose, dim3(step_grid(c, a)), dim3(256), step_lds(a), c->stream, a, *next);
+  else
+    hipLaunchKernelGGL(k_gmh_accept, dim3(step_grid(c, a)), dim3(256), step_lds(a), c->stream, a);
   MI355_HIP(hipGetLastError());
   return 0;
 }
 
-// (Re)capture kGraphSteps MH steps whose counters come from g->dyn.  The caller has run at least
-// one step directly since the last (re)initialisation, so every scratch buffer has its final size.
+// (Re)capture kGraphSteps MH steps whose counters come from g->dyn; a replay starts from a pending
+// proposal and leaves one.  The caller has run at least one step directly since the last
+// (re)initialisation, so every scratch buffer has its final size.
 static int build_graph(mi355_ctx* c) {
   GmhState* g = c->gmh;
   if (g->graph_exec && g->graph_version == g->version &&
@@ -200,10 +220,17 @@ static int build_graph(mi355_ctx* c) {
   hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
   int rc = 0;
   if (e == hipSuccess) {
-    for (int t = 0; t < kGraphSteps && rc == 0; ++t) {   // counters ping-pong between two slots
+    // each captured step: likelihood of the pending proposal, accept + proposal of the next step;
+    // counters ping-pong between two slots
+    for (int t = 0; t < kGraphSteps && rc == 0; ++t) {
       a.dyn = g->dyn.p + (t & 1);
       a.dyn_next = g->dyn.p + ((t & 1) ^ 1);
-      rc = launch_step(c, a);
+      rc = launch_lnl(c, a);
+      if (rc == 0) {
+        GmhArgs nx = a;                                    // (its counters: k_gmh_accept_propose, from a.dyn)
+        nx.dyn_next = nullptr;
+        rc = launch_accept(c, a, &nx);
+      }
     }
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
@@ -284,29 +311,8 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     return 0;
   }
   int64_t row = 0;
-  int64_t t0 = 0;
-  if (!inj_n && c->nkeep == 0 && nsteps >= kGraphMinSteps) {
-    // free-running production steps: one step directly (sizes every scratch buffer), then
-    // replays of a captured graph of kGraphSteps steps, the remainder directly
-    GmhArgs a = base_args(c);
-    a.blk = c->nblock ? static_cast<int>(c->stage_step % c->nblock) : 0;
-    a.step = c->step_total;
-    a.nsamp = c->nsamp;
-    int rc = launch_step(c, a);
-    if (rc) return rc;
-    t0 = 1;
-    rc = build_graph(c);
-    if (rc) return rc;
-    GmhDyn d{c->step_total + 1, c->nsamp + 1,
-             c->nblock ? static_cast<int32_t>((c->stage_step + 1) % c->nblock) : 0, 0};
-    MI355_HIP(hipMemcpyAsync(g->dyn.p, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
-    MI355_HIP(hipStreamSynchronize(c->stream));   // d lives on this stack frame
-    while (nsteps - t0 >= g->graph_steps) {
-      MI355_HIP(hipGraphLaunch(g->graph_exec, c->stream));
-      t0 += g->graph_steps;
-    }
-  }
-  for (int64_t t = t0; t < nsteps; ++t) {
+  // the arguments of step t of this run (counters, injected draws, trace row)
+  auto step_args = [&](int64_t t) {
     GmhArgs a = base_args(c);
     a.blk = c->nblock ? static_cast<int>((c->stage_step + t) % c->nblock) : 0;
     a.step = c->step_total + t;
@@ -315,13 +321,51 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
       a.inj_n = g->stage_a.p + static_cast<size_t>(t) * N * P;
       a.inj_u = g->stage_b.p + static_cast<size_t>(t) * N;
     }
+    return a;
+  };
+  // step t from its pending proposal: likelihood, accept, and the proposal of step t + 1 unless it is the last
+  auto run_step = [&](int64_t t) {
+    GmhArgs a = step_args(t);
     if (c->nkeep > 0 && (t + 1) % thin == 0 && row < c->nkeep) {
       a.tr_theta = c->tr_theta.p + static_cast<size_t>(row) * P * N;
       a.tr_lnPr = c->tr_lnPr.p + static_cast<size_t>(row) * N;
       a.tr_acc = c->tr_acc.p + static_cast<size_t>(row) * N;
       ++row;
     }
-    int rc = launch_step(c, a);
+    int rc = launch_lnl(c, a);
+    if (rc) return rc;
+    if (t + 1 < nsteps) {
+      const GmhArgs nx = step_args(t + 1);
+      return launch_accept(c, a, &nx);
+    }
+    return launch_accept(c, a, nullptr);
+  };
+  {
+    const int rc = launch_propose(c, step_args(0));
+    if (rc) return rc;
+  }
+  int64_t t0 = 0;
+  if (!inj_n && c->nkeep == 0 && nsteps >= kGraphMinSteps) {
+    // free-running production steps: one step directly (sizes every scratch buffer), then
+    // replays of a captured graph of kGraphSteps steps, the remainder directly
+    int rc = run_step(0);
+    if (rc) return rc;
+    t0 = 1;
+    rc = build_graph(c);
+    if (rc) return rc;
+    GmhDyn d{c->step_total + 1, c->nsamp + 1,
+             c->nblock ? static_cast<int32_t>((c->stage_step + 1) % c->nblock) : 0, 0};
+    MI355_HIP(hipMemcpyAsync(g->dyn.p, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    MI355_HIP(hipStreamSynchronize(c->stream));   // d lives on this stack frame
+    // (a replay ends with the proposal of the step behind it: the last step of the run stays outside, its
+    // launch has no proposal to make)
+    while (nsteps - t0 > g->graph_steps) {
+      MI355_HIP(hipGraphLaunch(g->graph_exec, c->stream));
+      t0 += g->graph_steps;
+    }
+  }
+  for (int64_t t = t0; t < nsteps; ++t) {
+    const int rc = run_step(t);
     if (rc) return rc;
   }
   c->step_total += nsteps;

@@ -15,6 +15,7 @@
 #include "beam_device.hpp"
 #include "philox.hpp"
 #include "sed_device.hpp"
+#include "fastmath.hpp"
 
 namespace mi355 {
 
@@ -101,6 +102,8 @@ struct GmhArgs {
   double* theta_new;        // [P][N]
   double* prior_new;        // [N]
   double* lnl_new;          // [N]
+  const double* lnl_partial;   // non-null: lnL[n] = -1/2 sum_j lnl_partial[n][j], j < lnl_nchunk ascending,
+  int lnl_nchunk;              // the finish of the beam chi-square (k_beam_finish) folded into the accept step
   double* zbuf;             // [P][N] scratch normals (correlated / rotated modes)
   const double* L;          // [P][P][N] sqrtMatrix per chain (modes 1, 2)
   const int32_t* block_of;  // [P]
@@ -148,13 +151,13 @@ struct GmhLane {
   int64_t n;
   bool valid;
 };
-__device__ __forceinline__ GmhLane gmh_lane(const GmhArgs& a) {
+__device__ __forceinline__ GmhLane gmh_lane(const GmhArgs& a, int64_t vblock) {
   GmhLane t;
   t.cb = 1 << a.cb_shift;
   t.G = 256 >> a.cb_shift;
   t.cl = threadIdx.x & (t.cb - 1);
   t.grp = threadIdx.x >> a.cb_shift;
-  t.n = static_cast<int64_t>(blockIdx.x) * t.cb + t.cl;
+  t.n = vblock * t.cb + t.cl;
   t.valid = t.n < a.N;
   return t;
 }
@@ -179,6 +182,202 @@ __device__ __forceinline__ void gmh_tri_decode(int e, int& i, int& j) {
   while (i * (i + 1) / 2 > e) --i;
   while ((i + 1) * (i + 2) / 2 <= e) ++i;
   j = e - i * (i + 1) / 2;
+}
+
+// getNewParams (Proposal.py:127-164) + package + prior for every chain
+// (the body of k_gmh_propose for block `vblock` of the grid; k_gmh_accept_propose runs it for the next
+// step behind the accept of this one)
+// LDS: z[P][cb] doubles
+__device__ __forceinline__ void gmh_propose_block(GmhArgs a, int64_t vblock, double* gmh_lds) {
+  const GmhLane t = gmh_lane(a, vblock);
+  const int P = a.pb.P;
+  const int64_t N = a.N, n = t.n;
+  const bool inject = a.inj_n != nullptr;
+  if (a.dyn) {
+    a.step = a.dyn->step;
+    a.blk = a.dyn->blk;
+  }
+  const uint64_t base = static_cast<uint64_t>(a.step) * a.npn;
+  double* z = gmh_lds;
+  if (a.mode == GMH_UNCORR) {
+    if (t.valid) {
+      for (int i0 = 2 * t.grp; i0 < P; i0 += 2 * t.G) {
+        const int i1 = i0 + 1;
+        const bool in0 = gmh_in_block(a, i0), in1 = i1 < P && gmh_in_block(a, i1);   // :151
+        double z0, z1;
+        if (inject) {
+          z0 = in0 ? a.inj_n[n * P + i0] : 0.0;
+          z1 = in1 ? a.inj_n[n * P + i1] : 0.0;
+        } else {
+          gmh_normal_pair(a, n, in0, in1, base + (in0 ? a.rank_in_block[i0] : 0),
+                          base + (in1 ? a.rank_in_block[i1] : 0), z0, z1);
+        }
+        double v = a.theta[i0 * N + n];
+        if (in0) v += z0 * a.sigma[i0 * N + n];            // :156-159
+        a.theta_new[i0 * N + n] = v;
+        if (i1 < P) {
+          v = a.theta[i1 * N + n];
+          if (in1) v += z1 * a.sigma[i1 * N + n];
+          a.theta_new[i1 * N + n] = v;
+        }
+      }
+    }
+  } else {
+    // the normals of the step into LDS, then one matrix row per (chain, group) turn
+    if (t.valid) {
+      if (a.mode == GMH_CORR) {                            // z_j = normal(base + j), all j
+        if (inject) {
+          for (int j = t.grp; j < P; j += t.G) z[j * t.cb + t.cl] = a.inj_n[n * P + j];
+        } else {
+          const int odd = static_cast<int>(base & 1);
+          for (int q = t.grp; 2 * q - odd < P; q += t.G) {
+            const int j0 = 2 * q - odd, j1 = j0 + 1;
+            double za, zb;
+            philox_normal2(a.seed, RNG_NORMAL, n, (base >> 1) + q, za, zb);
+            if (j0 >= 0) z[j0 * t.cb + t.cl] = za;
+            if (j1 < P) z[j1 * t.cb + t.cl] = zb;
+          }
+        }
+      } else {                                             // rotated: the block's normals by rank
+        for (int j = t.grp; j < P; j += t.G)
+          if (gmh_in_block(a, j))
+            z[j * t.cb + t.cl] = inject ? a.inj_n[n * P + a.rank_in_block[j]]
+                                        : philox_normal(a.seed, RNG_NORMAL, n, base + a.rank_in_block[j]);
+      }
+    }
+    __syncthreads();
+    if (t.valid) {
+      for (int i = t.grp; i < P; i += t.G) {
+        double v = a.theta[i * N + n];
+        const double* Li = a.L + static_cast<int64_t>(i) * P * N + n;
+        if (a.mode == GMH_CORR) {
+          if (gmh_in_block(a, i)) {                        // :153-159
+            double s = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < P; ++j) s += Li[j * N] * z[j * t.cb + t.cl];
+            v += s * a.sigma[i * N + n];
+          }
+        } else {                                           // :145-148, sum() starts from 0
+          double s = 0.0;
+          for (int j = 0; j < P; ++j)
+            if (gmh_in_block(a, j)) s += Li[j * N] * z[j * t.cb + t.cl];
+          v += s * a.sigma[i * N + n];
+        }
+        a.theta_new[i * N + n] = v;
+      }
+    }
+  }
+  __syncthreads();                                         // theta_new of the block's chains is complete
+  if (t.valid && t.grp == 0)
+    a.prior_new[n] = gmh_package_prior(a.pb, a.theta_new + n, N);   // :164, MCMC.py:245
+}
+
+// accept / reject (MCMC.py:236-279), running moments (:290-340), trace
+// LDS: d[P][cb] doubles + accepted[cb] doubles
+__device__ __forceinline__ void gmh_accept_block(GmhArgs a, int64_t vblock, double* gmh_lds) {
+  const double* e2t = kExp2Table;   // the accept test's exp as in the fused kernels; one lane per chain
+                                    // uses it once, so the table is read where it lies (no LDS copy)
+  const GmhLane t = gmh_lane(a, vblock);
+  const int P = a.pb.P;
+  const int64_t N = a.N, n = t.n;
+  if (a.dyn) {
+    a.step = a.dyn->step;
+    a.nsamp = a.dyn->nsamp;
+    a.blk = a.dyn->blk;
+  }
+  double* d = gmh_lds;
+  double* dec = gmh_lds + P * t.cb;
+  if (t.valid && t.grp == 0) {
+    const double prior = a.prior_new[n];
+    double v;
+    if (a.lnl_partial) {                                   // k_beam_finish's sum, NormalizedBeamLikelihood.py:16
+      double s = 0.0;
+      for (int j = 0; j < a.lnl_nchunk; ++j) s += a.lnl_partial[n * a.lnl_nchunk + j];
+      v = -0.5 * s;
+    } else {
+      v = a.lnl_new[n];
+    }
+    const double prev = a.lnPr[n];
+    bool accepted = false;
+    const bool bad = (v != v) || (v == -__builtin_inf());  // :238-243
+    if (prior > 0.0 && !bad) {
+      if (prior != 1.0) v += log(prior);                   // :250
+      const double lnalpha = v - prev;                     // :251-252
+      bool reject = false;
+      if (!(lnalpha >= 0.0)) {
+        const double u = a.inj_u ? a.inj_u[n]
+                                 : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
+        reject = !(exp_accept(lnalpha, e2t) > u);          // :264
+      }
+      accepted = !reject;
+    }
+    if (accepted) {
+      a.lnPr[n] = v;
+      a.naccept[n] += 1;                                   // :269
+      if (a.nblock) a.accept[static_cast<int64_t>(a.blk) * N + n] += 1;   // :271
+    }
+    if (a.tr_theta) {
+      a.tr_lnPr[n] = accepted ? v : prev;
+      a.tr_acc[n] = accepted ? 1 : 0;
+    }
+    dec[t.cl] = accepted ? 1.0 : 0.0;
+    if (n == 0 && a.dyn_next) {                            // next step's counters (graph replay):
+      GmhDyn nx;                                           // the other slot, nobody reads it now
+      nx.step = a.step + 1;
+      nx.nsamp = a.nsamp + 1;
+      nx.blk = a.nblock ? ((a.blk + 1 == a.nblock) ? 0 : a.blk + 1) : 0;
+      nx.pad = 0;
+      *a.dyn_next = nx;
+    }
+  }
+  __syncthreads();
+  const double cnt = static_cast<double>(a.nsamp + 1);
+  const double rn = rcp_nr(cnt);                           // as the fused kernel
+  const double cf = 1.0 - rn;
+  if (t.valid) {
+    const bool accepted = dec[t.cl] != 0.0;
+#pragma unroll 4
+    for (int i = t.grp; i < P; i += t.G) {
+      double x = a.theta[i * N + n];
+      if (accepted) {
+        x = a.theta_new[i * N + n];
+        a.theta[i * N + n] = x;
+      }
+      const double mu = a.mean[i * N + n];
+      const double dlt = x - mu;
+      d[i * t.cb + t.cl] = dlt;
+      const double mu1 = fma(dlt, rn, mu);                // the same FMAs as the fused kernel
+      a.mean[i * N + n] = mu1;
+      a.m2[i * N + n] = fma(dlt, x - mu1, a.m2[i * N + n]);
+      if (a.tr_theta) a.tr_theta[i * N + n] = x;
+    }
+  }
+  if (a.comom == nullptr) return;                          // uniform over the grid
+  __syncthreads();
+  if (!t.valid) return;
+  // C_ij += (n-1)/n d_i d_j with d = x - mean_old, j <= i (symmetric by construction); the
+  // triangle's entries are dealt round-robin to the groups, eight loads in flight per thread
+  const int T = P * (P + 1) / 2;
+  constexpr int U = 8;
+  for (int e0 = t.grp; e0 < T; e0 += t.G * U) {
+    double* ptr[U];
+    double inc[U], cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * t.G;
+      ptr[u] = nullptr;
+      if (e < T) {
+        int i, j;
+        gmh_tri_decode(e, i, j);
+        ptr[u] = a.comom + (static_cast<int64_t>(i) * P + j) * N + n;
+        inc[u] = cf * d[i * t.cb + t.cl] * d[j * t.cb + t.cl];
+        cur[u] = *ptr[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ptr[u]) *ptr[u] = cur[u] + inc[u];
+  }
 }
 
 }  // namespace mi355

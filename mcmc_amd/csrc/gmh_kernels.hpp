@@ -4,193 +4,36 @@
 
 namespace mi355 {
 
-// getNewParams (Proposal.py:127-164) + package + prior for every chain
-// dynamic LDS: z[P][cb] doubles
+// getNewParams + package + prior for every chain (gmh_propose_block, gmh_device.hpp); dynamic LDS: z[P][cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_propose(GmhArgs a) {
   extern __shared__ double gmh_lds[];
-  const GmhLane t = gmh_lane(a);
-  const int P = a.pb.P;
-  const int64_t N = a.N, n = t.n;
-  const bool inject = a.inj_n != nullptr;
-  if (a.dyn) {
-    a.step = a.dyn->step;
-    a.blk = a.dyn->blk;
-  }
-  const uint64_t base = static_cast<uint64_t>(a.step) * a.npn;
-  double* z = gmh_lds;
-  if (a.mode == GMH_UNCORR) {
-    if (t.valid) {
-      for (int i0 = 2 * t.grp; i0 < P; i0 += 2 * t.G) {
-        const int i1 = i0 + 1;
-        const bool in0 = gmh_in_block(a, i0), in1 = i1 < P && gmh_in_block(a, i1);   // :151
-        double z0, z1;
-        if (inject) {
-          z0 = in0 ? a.inj_n[n * P + i0] : 0.0;
-          z1 = in1 ? a.inj_n[n * P + i1] : 0.0;
-        } else {
-          gmh_normal_pair(a, n, in0, in1, base + (in0 ? a.rank_in_block[i0] : 0),
-                          base + (in1 ? a.rank_in_block[i1] : 0), z0, z1);
-        }
-        double v = a.theta[i0 * N + n];
-        if (in0) v += z0 * a.sigma[i0 * N + n];            // :156-159
-        a.theta_new[i0 * N + n] = v;
-        if (i1 < P) {
-          v = a.theta[i1 * N + n];
-          if (in1) v += z1 * a.sigma[i1 * N + n];
-          a.theta_new[i1 * N + n] = v;
-        }
-      }
-    }
-  } else {
-    // the normals of the step into LDS, then one matrix row per (chain, group) turn
-    if (t.valid) {
-      if (a.mode == GMH_CORR) {                            // z_j = normal(base + j), all j
-        if (inject) {
-          for (int j = t.grp; j < P; j += t.G) z[j * t.cb + t.cl] = a.inj_n[n * P + j];
-        } else {
-          const int odd = static_cast<int>(base & 1);
-          for (int q = t.grp; 2 * q - odd < P; q += t.G) {
-            const int j0 = 2 * q - odd, j1 = j0 + 1;
-            double za, zb;
-            philox_normal2(a.seed, RNG_NORMAL, n, (base >> 1) + q, za, zb);
-            if (j0 >= 0) z[j0 * t.cb + t.cl] = za;
-            if (j1 < P) z[j1 * t.cb + t.cl] = zb;
-          }
-        }
-      } else {                                             // rotated: the block's normals by rank
-        for (int j = t.grp; j < P; j += t.G)
-          if (gmh_in_block(a, j))
-            z[j * t.cb + t.cl] = inject ? a.inj_n[n * P + a.rank_in_block[j]]
-                                        : philox_normal(a.seed, RNG_NORMAL, n, base + a.rank_in_block[j]);
-      }
-    }
-    __syncthreads();
-    if (t.valid) {
-      for (int i = t.grp; i < P; i += t.G) {
-        double v = a.theta[i * N + n];
-        const double* Li = a.L + static_cast<int64_t>(i) * P * N + n;
-        if (a.mode == GMH_CORR) {
-          if (gmh_in_block(a, i)) {                        // :153-159
-            double s = 0.0;
-#pragma unroll 4
-            for (int j = 0; j < P; ++j) s += Li[j * N] * z[j * t.cb + t.cl];
-            v += s * a.sigma[i * N + n];
-          }
-        } else {                                           // :145-148, sum() starts from 0
-          double s = 0.0;
-          for (int j = 0; j < P; ++j)
-            if (gmh_in_block(a, j)) s += Li[j * N] * z[j * t.cb + t.cl];
-          v += s * a.sigma[i * N + n];
-        }
-        a.theta_new[i * N + n] = v;
-      }
-    }
-  }
-  __syncthreads();                                         // theta_new of the block's chains is complete
-  if (t.valid && t.grp == 0)
-    a.prior_new[n] = gmh_package_prior(a.pb, a.theta_new + n, N);   // :164, MCMC.py:245
+  gmh_propose_block(a, blockIdx.x, gmh_lds);
 }
 
-// accept / reject (MCMC.py:236-279), running moments (:290-340), trace
-// dynamic LDS: d[P][cb] doubles + accepted[cb] doubles
+// accept / reject, running moments, trace (gmh_accept_block); dynamic LDS: d[P][cb] doubles + accepted[cb] doubles
 __global__ __launch_bounds__(256) void k_gmh_accept(GmhArgs a) {
   extern __shared__ double gmh_lds[];
-  const double* e2t = kExp2Table;   // the accept test's exp as in the fused kernels; one lane per chain
-                                    // uses it once, so the table is read where it lies (no LDS copy)
-  const GmhLane t = gmh_lane(a);
-  const int P = a.pb.P;
-  const int64_t N = a.N, n = t.n;
-  if (a.dyn) {
-    a.step = a.dyn->step;
-    a.nsamp = a.dyn->nsamp;
-    a.blk = a.dyn->blk;
+  gmh_accept_block(a, blockIdx.x, gmh_lds);
+}
+
+// The accept of step t and the proposal of step t + 1 in one launch: both work chain by chain on the
+// same thread layout, and a step of a small job is bound by its launches (one 64 x 64 beam map, one
+// chain - the reference's own use, ProcessBeamData.py:277-279 - took four launches and 15.6 us per step
+// under hipGraph replay; two launches - this one and the chi-square, whose finish the accept does
+// itself, GmhArgs::lnl_partial - take half).  The same bodies in the same order: the same chain.
+// Under graph replay (acc.dyn) the proposal's counters are the accept's plus one step.
+__global__ __launch_bounds__(256) void k_gmh_accept_propose(GmhArgs acc, GmhArgs prop) {
+  extern __shared__ double gmh_lds[];
+  if (acc.dyn) {
+    const GmhDyn d = *acc.dyn;
+    prop.dyn = nullptr;
+    prop.step = d.step + 1;
+    prop.nsamp = d.nsamp + 1;
+    prop.blk = prop.nblock ? ((d.blk + 1 == prop.nblock) ? 0 : d.blk + 1) : 0;
   }
-  double* d = gmh_lds;
-  double* dec = gmh_lds + P * t.cb;
-  if (t.valid && t.grp == 0) {
-    const double prior = a.prior_new[n];
-    double v = a.lnl_new[n];
-    const double prev = a.lnPr[n];
-    bool accepted = false;
-    const bool bad = (v != v) || (v == -__builtin_inf());  // :238-243
-    if (prior > 0.0 && !bad) {
-      if (prior != 1.0) v += log(prior);                   // :250
-      const double lnalpha = v - prev;                     // :251-252
-      bool reject = false;
-      if (!(lnalpha >= 0.0)) {
-        const double u = a.inj_u ? a.inj_u[n]
-                                 : philox_uniform(a.seed, RNG_UNIFORM, n, static_cast<uint64_t>(a.step));
-        reject = !(exp_accept(lnalpha, e2t) > u);          // :264
-      }
-      accepted = !reject;
-    }
-    if (accepted) {
-      a.lnPr[n] = v;
-      a.naccept[n] += 1;                                   // :269
-      if (a.nblock) a.accept[static_cast<int64_t>(a.blk) * N + n] += 1;   // :271
-    }
-    if (a.tr_theta) {
-      a.tr_lnPr[n] = accepted ? v : prev;
-      a.tr_acc[n] = accepted ? 1 : 0;
-    }
-    dec[t.cl] = accepted ? 1.0 : 0.0;
-    if (n == 0 && a.dyn_next) {                            // next step's counters (graph replay):
-      GmhDyn nx;                                           // the other slot, nobody reads it now
-      nx.step = a.step + 1;
-      nx.nsamp = a.nsamp + 1;
-      nx.blk = a.nblock ? ((a.blk + 1 == a.nblock) ? 0 : a.blk + 1) : 0;
-      nx.pad = 0;
-      *a.dyn_next = nx;
-    }
-  }
-  __syncthreads();
-  const double cnt = static_cast<double>(a.nsamp + 1);
-  const double rn = rcp_nr(cnt);                           // as the fused kernel
-  const double cf = 1.0 - rn;
-  if (t.valid) {
-    const bool accepted = dec[t.cl] != 0.0;
-#pragma unroll 4
-    for (int i = t.grp; i < P; i += t.G) {
-      double x = a.theta[i * N + n];
-      if (accepted) {
-        x = a.theta_new[i * N + n];
-        a.theta[i * N + n] = x;
-      }
-      const double mu = a.mean[i * N + n];
-      const double dlt = x - mu;
-      d[i * t.cb + t.cl] = dlt;
-      const double mu1 = fma(dlt, rn, mu);                // the same FMAs as the fused kernel
-      a.mean[i * N + n] = mu1;
-      a.m2[i * N + n] = fma(dlt, x - mu1, a.m2[i * N + n]);
-      if (a.tr_theta) a.tr_theta[i * N + n] = x;
-    }
-  }
-  if (a.comom == nullptr) return;                          // uniform over the grid
-  __syncthreads();
-  if (!t.valid) return;
-  // C_ij += (n-1)/n d_i d_j with d = x - mean_old, j <= i (symmetric by construction); the
-  // triangle's entries are dealt round-robin to the groups, eight loads in flight per thread
-  const int T = P * (P + 1) / 2;
-  constexpr int U = 8;
-  for (int e0 = t.grp; e0 < T; e0 += t.G * U) {
-    double* ptr[U];
-    double inc[U], cur[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * t.G;
-      ptr[u] = nullptr;
-      if (e < T) {
-        int i, j;
-        gmh_tri_decode(e, i, j);
-        ptr[u] = a.comom + (static_cast<int64_t>(i) * P + j) * N + n;
-        inc[u] = cf * d[i * t.cb + t.cl] * d[j * t.cb + t.cl];
-        cur[u] = *ptr[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ptr[u]) *ptr[u] = cur[u] + inc[u];
-  }
+  gmh_accept_block(acc, blockIdx.x, gmh_lds);
+  __syncthreads();                                         // theta of the block's chains is final; LDS is free
+  gmh_propose_block(prop, blockIdx.x, gmh_lds);
 }
 
 // newMCMC (MCMC.py:343-413): centre = package(mean), stdevs = package(stdev), sigma =

@@ -18,5 +18,9 @@ int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn);
 int cl_mh_run(mi355_ctx* c, const GmhArgs& a, int64_t nsteps, int thin, int64_t nkeep);
 // BeamFit: number of maps and the prior box, beam_api.hip
 int beam_problem_info(const mi355_ctx* c, int64_t* M, BeamPriorBox* box);
+// BeamFit: the chi-square kernels of mi355_beam_lnlike_dev_async without their finish: partial sums
+// [nm * C][nchunk] on the device (the engine's accept step adds a row up itself: GmhArgs::lnl_partial)
+int beam_chi2_partials_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta_dev,
+                             const double** partial_out, int* nchunk_out);
 
 }  // namespace mi355
