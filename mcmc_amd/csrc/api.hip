@@ -274,7 +274,12 @@ struct LaunchRun {
       } else if (pe.G == 1 && pe.bs == kBlockThreads && a.mode == 1 && a.inj_n == nullptr) {
         // Cholesky-correlated, free-running, lane = chain in full blocks (its LDS columns are
         // kBlockThreads lanes apart): the instantiation compiled for that proposal
-        if (launch_lds((k_mh_run<M, true, true, 1, false, 1>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2;
+        // (with the running co-moments: the instantiation that keeps them in registers)
+        if (a.comom != nullptr) {
+          if (launch_lds((k_mh_run<M, true, true, 1, false, 2>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2;
+        } else {
+          if (launch_lds((k_mh_run<M, true, true, 1, false, 1>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2;
+        }
       } else if constexpr (M != MI355_SED_M2) {
         if (pe.G == 8)
           { if (launch_lds((k_mh_run<M, true, true, 8>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2; }

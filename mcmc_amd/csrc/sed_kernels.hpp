@@ -301,7 +301,12 @@ template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false
 __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>())) void k_mh_run(MhArgs a) {
   static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
   static_assert(!SINGLE || !EXT, "single-parameter blocks: plain sampler");
-  static_assert(XM == -1 || (XM == 1 && EXT && G == 1), "XM: the Cholesky-correlated extended sampler, lane = chain");
+  static_assert(XM == -1 || ((XM == 1 || XM == 2) && EXT && G == 1), "XM: the Cholesky-correlated extended sampler, lane = chain");
+  // XM = 2: XM = 1 with the running co-moments in registers for the launch (loaded before the first
+  // step, stored after the last) instead of a read-modify-write of the 21 entries in memory every step:
+  // the same additions in the same order on the same values.  Its own instantiation because the 42
+  // registers cost the launches without co-moments what the compiler spills for them.
+  constexpr bool CMR = (XM == 2);
   constexpr int P = ModelTraits<MODEL>::P;
   constexpr int NTRI = P * (P + 1) / 2;
   extern __shared__ double smem[];
@@ -396,11 +401,18 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
       for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j)
-          Ll[(i * (i + 1) / 2 + j) * (XM == 1 ? kBlockThreads : static_cast<int>(blockDim.x))] =
+          Ll[(i * (i + 1) / 2 + j) * (XM >= 1 ? kBlockThreads : static_cast<int>(blockDim.x))] =
               a.L[(static_cast<int64_t>(i) * P + j) * a.N + n];
     }
   }
 
+  double cmr[CMR ? NTRI : 1];                              // running co-moments (XM = 2)
+  if constexpr (CMR) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) cmr[i * (i + 1) / 2 + j] = a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n];
+  }
   const bool inject = a.inj_n != nullptr;
   const uint32_t allmask = (1u << P) - 1u;
   int blk = a.nblock ? static_cast<int>(a.stage_step % a.nblock) : 0;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
           th[i] = old + z * sg[i];                         // Proposal.py:151,156-159
           if constexpr (sed_prior_is_box<MODEL>()) moved_ok = sed_prior_one<MODEL>(i, th[i], a.k);
         }
-    } else if constexpr (EXT && XM == 1) {
+    } else if constexpr (EXT && XM >= 1) {
       // Cholesky-correlated, free-running: normal(step NPN + j) for every j (Proposal.py:150-154), the
       // step's uniform from the pair it shares with its neighbour
       constexpr int NPN = (P + 1) & ~1;
@@ -626,7 +638,13 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
       mu[i] = fma(dlt, rn, mu[i]);
       m2[i] = fma(dlt, th[i] - mu[i], m2[i]);
     }
-    if constexpr (EXT) {
+    if constexpr (CMR) {
+      const double cf = 1.0 - rn;                          // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) cmr[i * (i + 1) / 2 + j] = cmr[i * (i + 1) / 2 + j] + cf * dl[i] * dl[j];
+    } else if constexpr (EXT) {
       if (a.comom != nullptr && writer) {                  // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
         const double cf = 1.0 - rn;
         double cur[NTRI];
@@ -659,6 +677,12 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
   }
 
   if (!writer) return;
+  if constexpr (CMR) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n] = cmr[i * (i + 1) / 2 + j];
+  }
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     a.theta[i * a.N + n] = th[i];

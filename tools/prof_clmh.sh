@@ -11,7 +11,7 @@ mkdir -p $out
 cd $R
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tests/bench_clbeam.py mh $args > $out/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc1 -- python3 tests/bench_clbeam.py mh $args > $out/pmc1.log 2>&1 || true
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out/pmc2 -- python3 tests/bench_clbeam.py mh $args > $out/pmc2.log 2>&1 || true
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc2 -- python3 tests/bench_clbeam.py mh $args > $out/pmc2.log 2>&1 || true
 python3 - "$out" <<'PY'
 import csv, glob, sys
 root = sys.argv[1]
@@ -19,7 +19,7 @@ for tag in ("pmc1", "pmc2"):
     fs = glob.glob(root + "/%s/*/*counter_collection.csv" % tag)
     if not fs:
         print(tag, "no counter file"); continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if "k_cl_mh_run" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(fs[0])) if "k_cl_mh" in r["Kernel_Name"]]
     if not rows:
         print(tag, "kernel not found"); continue
     last = max(int(r["Dispatch_Id"]) for r in rows)
