@@ -33,9 +33,9 @@ PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 128 FP64 FLOP/clk x 2.4 GHz (MI355X vec
 # allocation changes.  State is read and written once per launch whatever the number of inner steps
 # (STATE_BYTES_PER_CHAIN, the algorithmic figure); the rest is the scratch of the VGPRs the
 # three-waves-per-SIMD register allocation spills.
-HBM_BYTES_PER_CHAIN_LAUNCH = 817.4
+HBM_BYTES_PER_CHAIN_LAUNCH = 801.5
 STATE_BYTES_PER_CHAIN = 415.7
-TRAFFIC_SOURCE = "profiles/r2_bench_summary.txt"
+TRAFFIC_SOURCE = "profiles/r3_bench_summary.txt"
 
 
 def _port_worker(job):
