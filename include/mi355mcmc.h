@@ -393,6 +393,17 @@ int mi355_gelman_rubin(mi355_ctx* ctx, int32_t nchain, int32_t P, const double* 
 int mi355_mh_ess(mi355_ctx* ctx, double* ess);
 /* Single-GPU convenience: all C chains are local.  rhat host [S, P]. */
 int mi355_rhat(mi355_ctx* ctx, double* rhat);
+/* Multi-GPU mi355_rhat behind the header alone: one process per GPU, every rank holds C chains of the
+ * same S sources (chain-sharded layout) and calls this with its communicator; Ctot = chains per source
+ * over all ranks.  Replaces gelmanrubin_MCMC over the chains of all ranks (convergence.py:58-87,
+ * driver.py:247-249).  rccl_comm is the caller's ncclComm_t (RCCL; passed as void* so that this header
+ * needs no rccl.h).  Two all-reduces (SUM, FP64) of S*P and 2*S*P doubles on the context stream between
+ * the partial-sum kernels; asynchronous; rhat_dev [P, S] on the device (the layout of
+ * mi355_rhat_finish_async).  The library does not link RCCL: it binds ncclAllReduce from the RCCL the
+ * process has loaded (the caller's own, or torch's), else from librccl.so on the loader path, and fails
+ * with an error if there is none.  mcmc_amd.distributed.engine_rhat does the same through
+ * torch.distributed. */
+int mi355_rhat_allreduce_async(mi355_ctx* ctx, void* rccl_comm, int64_t Ctot, double* rhat_dev);
 /* mi355_rhat for callers that cannot allocate.  It has no counterpart in the reference; it is for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
  * kernels as mi355_rhat, but the intermediates (chain-mean sums, centred sums) live in a fixed

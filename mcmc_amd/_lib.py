@@ -124,6 +124,7 @@ SIGNATURES = {
     "mi355_gelman_rubin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "mi355_rhat": (C.c_int, [C.c_void_p, c_double_p]),
     "mi355_rhat_noalloc_async": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_rhat_allreduce_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mi355_mh_ess": (C.c_int, [C.c_void_p, c_double_p]),
 }
 

@@ -1,5 +1,7 @@
 // C ABI of libmi355mcmc.so (declared in include/mi355mcmc.h): context, SED catalogue,
 // batched likelihood, Metropolis-Hastings state machine, Gelman-Rubin.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -1152,6 +1154,48 @@ int mi355_rhat_noalloc_async(mi355_ctx* c, double* rhat_dev) {
   rc = mi355_rhat_partial_async(c, 1, gmean, sums);
   if (rc) return rc;
   return mi355_rhat_finish_async(c, sums, c->C, rhat_dev);
+}
+
+// ncclAllReduce of the RCCL this process runs with (see the header): bound once
+typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static rccl_allreduce_fn rccl_allreduce() {
+  static rccl_allreduce_fn fn = [] {
+    void* s = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!s) {
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) s = dlsym(h, "ncclAllReduce");
+    }
+    return reinterpret_cast<rccl_allreduce_fn>(s);
+  }();
+  return fn;
+}
+
+int mi355_rhat_allreduce_async(mi355_ctx* c, void* rccl_comm, int64_t Ctot, double* rhat_dev) {
+  MI355_REQUIRE(c && c->mh_ready && rhat_dev, "mi355_rhat_allreduce: bad argument");
+  MI355_REQUIRE(rccl_comm, "mi355_rhat_allreduce: null communicator");
+  MI355_REQUIRE(Ctot >= 2 && Ctot >= c->C, "mi355_rhat_allreduce: Ctot=%lld chains per source over all ranks (this rank holds %d)",
+                static_cast<long long>(Ctot), c->C);
+  const rccl_allreduce_fn allreduce = rccl_allreduce();
+  MI355_REQUIRE(allreduce, "mi355_rhat_allreduce: no RCCL in this process (ncclAllReduce not found, librccl.so not loadable)");
+  MI355_HIP(hipSetDevice(c->device));
+  const int64_t n = c->mhS * c->mhP;
+  if (c->scratch_a.alloc(static_cast<size_t>(n) * 3)) return -2;
+  double* gmean = c->scratch_a.p;
+  double* sums = c->scratch_a.p + n;
+  constexpr int kNcclFloat64 = 8, kNcclSum = 0;            // rccl.h: ncclFloat64, ncclSum
+  int rc = mi355_rhat_partial_async(c, 0, nullptr, gmean);
+  if (rc) return rc;
+  int nrc = allreduce(gmean, gmean, static_cast<size_t>(n), kNcclFloat64, kNcclSum, rccl_comm, c->stream);
+  MI355_REQUIRE(nrc == 0, "mi355_rhat_allreduce: ncclAllReduce failed with ncclResult_t %d", nrc);
+  hipLaunchKernelGGL(k_scale, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, c->stream,
+                     n, 1.0 / static_cast<double>(Ctot), gmean);
+  MI355_HIP(hipGetLastError());
+  rc = mi355_rhat_partial_async(c, 1, gmean, sums);
+  if (rc) return rc;
+  nrc = allreduce(sums, sums, static_cast<size_t>(2 * n), kNcclFloat64, kNcclSum, rccl_comm, c->stream);
+  MI355_REQUIRE(nrc == 0, "mi355_rhat_allreduce: ncclAllReduce failed with ncclResult_t %d", nrc);
+  return mi355_rhat_finish_async(c, sums, Ctot, rhat_dev);
 }
 
 int mi355_rhat(mi355_ctx* c, double* rhat) {
