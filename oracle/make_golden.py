@@ -563,6 +563,26 @@ def golden_cl(R):
             g["two__obs"], g["two__N_inv"] = d2.obs, d2.N_inv
             g["two__xfactors"], g["two__has_xfactor"] = d2.xfactors, d2.has_xfactor
             g["two__calib"] = 0.03
+            # a draw-injected block stage on the full 11 x 11 calibration x beam grid (:317-372)
+            r = np.random.default_rng(199)
+            nrows = 400
+            inj = Injector(r.standard_normal((nrows, npar)), r.uniform(size=nrows))
+            Prop.normal = inj.normal
+            MC.uniform = inj.uniform
+            like1 = BL.binnedClLikelihood(data=[d], model=BM.binnedClModel)
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                mg = MC.MCMC(like1, startProposal=np.full(npar, 0.05), startParams=truth.copy(), doBlock=True)
+                kg0 = inj.k
+                mg.MC_append(150)
+            g["grid121__c0_samples"] = mg.samples.copy()
+            g["grid121__c0_lnPr"] = mg.lnPr.copy()
+            g["grid121__c0_accepted"] = mg.accepted.astype(bool)
+            g["grid121__c0_naccept"] = mg.naccept
+            g["grid121__accept0"] = mg.accept.copy()
+            g["grid121__k"] = np.array([kg0, inj.k])
+            g["grid121__normals"] = inj.normals[:inj.k].copy()
+            g["grid121__uniforms"] = inj.uniforms[:inj.k].copy()
+            print("cl 11 x 11 chain: naccept", mg.naccept, "draw rows", inj.k)
         if name == "xcalib":
             # draw-injected chains: block stage, then newMCMC(rotateParams=True) and a
             # Cholesky-correlated all-parameter stage (test_binnedCl.py:177 uses rotateParams)

@@ -89,6 +89,34 @@ def test_cl_reference_chains_block_rotated_correlated(fused):
         replay(eng, g, "c2", k[4], 200, P)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_cl_reference_chain_on_the_11x11_grid(fused):
+    """The reference's own chain on a data set with calibration AND beam uncertainty - the full 11 x 11
+    numeric marginalisation of ClData_CosmoMC.py:317-372, config C4's shape - draw for draw: through the
+    fused kernel (replica waves share out the 121 points, csrc/cl_mhw_kernels.hpp) and through the
+    launch-per-step engine."""
+    g = load("cl_g5.npz")
+    eng, model = cl_engine(g, "xcalibbeam")
+    P = model.nparam
+    k = g["grid121__k"]
+    with eng:
+        eng.mh_set_fused(fused)
+        eng.mh_init_problem("cl", 1, g["grid121__c0_samples"][0], np.full(P, 0.05), param_blocks=np.arange(P),
+                            randomize_start=False)
+        assert eng.mh_fused_active == fused
+        n = 150
+        zn = g["grid121__normals"][k[0]:k[0] + n, None, :P]
+        zu = g["grid121__uniforms"][k[0]:k[0] + n, None]
+        eng.mh_run(n, thin=1, inj_normals=np.ascontiguousarray(zn), inj_uniforms=np.ascontiguousarray(zu))
+        s, l, a = eng.mh_trace()
+        assert np.array_equal(a[:, 0, 0], g["grid121__c0_accepted"][1:])
+        np.testing.assert_allclose(s[:, 0, 0], g["grid121__c0_samples"][1:], rtol=RTOL, atol=1e-15)
+        np.testing.assert_allclose(l[:, 0, 0], g["grid121__c0_lnPr"][1:], rtol=RTOL)
+        mom = eng.mh_moments()
+        assert int(mom["naccept"][0, 0]) == int(g["grid121__c0_naccept"])
+        assert np.array_equal(mom["accept"][0, 0], g["grid121__accept0"])
+
+
 def test_beam_reference_chains():
     from mcmc_amd import Engine
     g = load("beam_g6.npz")
