@@ -135,9 +135,9 @@ struct LaunchStart {
   }
 };
 
-// Every source of the catalogue is in the domain of the clamp-free kernels (the incremental and the
-// extended samplers have no exact-path instantiation: mixed catalogues run k_mh_run / the step-wise
-// engine, source by source).
+// Every source of the catalogue is in the domain of the clamp-free kernels (the (chain, band) lane
+// mapping needs that; the plain, extended and incremental samplers split a mixed catalogue into two
+// launches over disjoint lists of chain blocks).
 static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c->nslow == 0; }
 
 // Block size and lanes per chain of the next k_mh_run launch (ext: its extended instantiation, which
@@ -212,7 +212,8 @@ static bool incremental_applies(const mi355_ctx* c) {
   if (!c->incremental || !c->mh_ready || gmh_active(c)) return false;
   const int m = c->model.model;
   if (m != MI355_SED_M2N && m != MI355_SED_M2N_LOGA) return false;
-  if (!sed_all_fast(c) || c->nb_most > kIncBands || c->nblock != c->mhP || c->npn != 1) return false;
+  // (a mixed catalogue: the blocks with a source outside the fast domain run the plain per-lane kernel beside it)
+  if (c->kc.fast_ok == 0.0 || c->nb_most > kIncBands || c->nblock != c->mhP || c->npn != 1) return false;
   for (int b = 0; b < c->nblock; ++b)
     if (c->blockmask[b] != (1u << b)) return false;
   return true;
@@ -237,7 +238,24 @@ struct LaunchRun {
     if constexpr (M == MI355_SED_M2N || M == MI355_SED_M2N_LOGA) {
       const size_t lds_inc = lds + 2 * static_cast<size_t>(kIncBands) * bs * sizeof(double);
       if (incremental_applies(c) && lds_inc <= kLdsLimit) {
-        { if (launch_lds(k_mh_run_inc<M>, grid, bs, lds_inc, c->stream, a)) return -2; }
+        if (sed_all_fast(c)) {
+          if (launch_lds(k_mh_run_inc<M>, grid, bs, lds_inc, c->stream, a)) return -2;
+        } else {
+          // mixed catalogue, as the plain sampler below: the slow blocks through the per-lane kernel on stream2
+          if (build_block_lists(c, bs)) return -2;
+          MhArgs af = a, as = a;
+          af.blocklist = c->blk_fast.p;
+          as.blocklist = c->blk_slow.p;
+          MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
+          MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+          if (launch_lds((k_mh_run<M, false>), static_cast<unsigned>(c->nblk_slow), bs, lds, c->stream2, as)) return -2;
+          MI355_HIP(hipGetLastError());
+          MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
+          if (c->nblk_fast > 0) {
+            if (launch_lds(k_mh_run_inc<M>, static_cast<unsigned>(c->nblk_fast), bs, lds_inc, c->stream, af)) return -2;
+          }
+          MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
         MI355_HIP(hipGetLastError());
         if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
         if (!c->capturing) c->ev_valid = true;

@@ -723,7 +723,9 @@ __global__ __launch_bounds__(kBlockThreads, 3) void k_mh_run_inc(MhArgs a) {
   const int slot = kIncBands * blockDim.x;                 // doubles per cache slot
   double* tables = smem + 2 * slot;
   const int stride = kBandFields * a.nbm;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  // (a mixed catalogue hands this kernel the list of chain blocks whose sources are all fast)
+  const int64_t bidx = a.blocklist ? a.blocklist[blockIdx.x] : blockIdx.x;
+  const int64_t n0 = bidx * blockDim.x;
   const int64_t n_last = min(n0 + blockDim.x, a.N) - 1;
   const int64_t s_first = n0 / a.C;
   const int nsrc = static_cast<int>(n_last / a.C - s_first) + 1;

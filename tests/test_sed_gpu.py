@@ -436,6 +436,37 @@ def test_catalogue_outside_the_fast_path_domain(eng, mid):
     np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
 
 
+def test_incremental_sampler_splits_a_mixed_catalogue():
+    """The incremental sampler on a catalogue with a radio point: the chain blocks that hold such a source
+    run the plain per-lane kernel, all the others k_mh_run_inc beside them - the same chains as the plain
+    sampler gives on the same catalogue (which the test below pins source by source)."""
+    from mcmc_amd import Engine
+    mid, S, C, P, nsteps = R.M2N, 70, 16, 6, 60
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=23)
+    nu2 = nu.copy()
+    nu2[[3, 41], 0] = 1.4
+    nb = np.full(S, 8, np.int32)
+    start = truth[:, None, :P].repeat(C, axis=1)
+    out = []
+    for inc in (True, False):
+        with Engine(seed=77) as e:
+            e.sed_load(mid, nb, nu2, d, sig)
+            assert e.sed_fast_sources == S - 2
+            e.mh_set_incremental(inc)
+            e.mh_init(C, start, np.full(P, 0.03), param_blocks=np.arange(P), randomize_start=False)
+            assert e.mh_incremental_active == inc
+            e.mh_run(nsteps, thin=1)
+            tr, lp, acc = e.mh_trace()
+            e.mh_run(25)
+            out.append((tr, lp, acc, e.mh_moments()))
+    # (the incremental evaluation sums a chain's chi-square from cached band terms: lnPr agrees to rounding,
+    # the decisions and therefore the samples are the same)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12)
+    for k, v in out[0][3].items():
+        np.testing.assert_allclose(v, out[1][3][k], rtol=1e-12, err_msg=k)
+
+
 @pytest.mark.parametrize("mid,C", [(R.M2N, 16), (R.M1N, 100), (R.THICK, 64)])
 def test_mixed_catalogue_splits_source_by_source(mid, C):
     """One radio point must not move a whole catalogue to the exact path: the sources with a band
