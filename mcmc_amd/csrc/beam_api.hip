@@ -14,7 +14,7 @@ struct BeamProblem {
   int xy_per_map = 0, sig_kind = 0;
   BeamPriorBox box{};
   DevBuf<double> x, y, d, w, sig;
-  DevBuf<double> xyref;            // [1 or M][2] midpoint of the coordinates' bounding box (beam_fold)
+  DevBuf<double> xyref;            // [1 or M][4] midpoint and half extents of the coordinates' bounding box (beam_fold)
   DevBuf<double> mono;             // one shared grid: [5][mstride] its monomials (k_beam_chi2_cl)
   int64_t mstride = 0;
   double xr = 0.0, yr = 0.0, hx = 0.0, hy = 0.0;   // reference point and half extents of the shared grid
@@ -98,14 +98,17 @@ int mi355_beam_load(mi355_ctx* c, int64_t M, int64_t npix, const double* x, cons
   }
   // reference point of every coordinate set: the midpoint of its finite extent
   const size_t nref = xy_per_map ? static_cast<size_t>(M) : 1;
-  std::vector<double> ref(2 * nref, 0.0);
+  std::vector<double> ref(4 * nref, 0.0);                 // (xr, yr, hx, hy) per coordinate set
   for (size_t r = 0; r < nref; ++r)
     for (int ax = 0; ax < 2; ++ax) {
       const double* v = (ax ? y : x) + r * static_cast<size_t>(npix);
       double lo = INFINITY, hi = -INFINITY;
       for (int64_t i = 0; i < npix; ++i)
         if (std::isfinite(v[i])) { lo = std::fmin(lo, v[i]); hi = std::fmax(hi, v[i]); }
-      if (lo <= hi) ref[2 * r + ax] = lo + 0.5 * (hi - lo);
+      if (lo <= hi) {
+        ref[4 * r + ax] = lo + 0.5 * (hi - lo);
+        ref[4 * r + 2 + ax] = 0.5 * (hi - lo);
+      }
       if (lo <= hi && r == 0) (ax ? p->hy : p->hx) = 0.5 * (hi - lo);
     }
   if (p->xyref.alloc(ref.size())) return -2;

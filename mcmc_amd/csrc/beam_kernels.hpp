@@ -100,6 +100,17 @@ __device__ __forceinline__ void beam_fold(const double* k, double xr, double yr,
 
 // NCH: chains of the block that exist (1 .. kBeamCH): a block of one chain - the reference's own use -
 // runs one chain's instructions, not eight; a chain's arithmetic does not depend on NCH
+// The monomial form is as accurate as its largest term allows: the terms reach `big` = the form's
+// coefficients times the grid's half extents and cancel to the exponent near the chain's centre, an
+// absolute error of about 3 big 2^-53 in the exponent = relative in the model value.  Chains whose form
+// exceeds 1024 on the grid (a map more than ~35 beam widths across: 4e-13) count as irregular - the
+// block / wave runs the reference's operation order for them (beam_model_at) - and so do non-finite ones.
+__device__ __forceinline__ bool beam_form_ok(const double* f, double hx, double hy) {
+  const double big = fabs(f[0]) * hx * hx + fabs(f[1]) * hy * hy + fabs(f[2]) * hx * hy + fabs(f[3]) * hx +
+                     fabs(f[4]) * hy + fabs(f[5]);
+  return big < 1024.0;                                     // (false for NaN)
+}
+
 template <bool WPIX, bool PLANE, int NCH>
 __device__ __forceinline__ void beam_pixel_fast(const double (*f)[kBeamNF], const double* e2t,
                                                 double xs, double ys, double dv, double w,
@@ -140,7 +151,8 @@ struct BeamArgs {
   int C;                  // chains per map
   int64_t n;              // nm * C parameter vectors
   const double* theta;    // [9][n] parameter-major, vector e = (m - m0)*C + c
-  const double* xyref;    // [1][2] or [M][2]: the reference point of every map's coordinates (beam_fold)
+  const double* xyref;    // [1][4] or [M][4]: reference point (xr, yr) of every map's coordinates (beam_fold) and
+                          // their half extents (hx, hy) around it
   int chunk;              // pixels per block (multiple of 256)
   int nchunk;
   double* partial;        // [n][nchunk]
@@ -161,7 +173,8 @@ __device__ __forceinline__ void beam_group_consts(const BeamArgs& a, int64_t ml,
   const int64_t m = a.m0 + ml;
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
-  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 2], yr = a.xyref[(a.xy_per_map ? m : 0) * 2 + 1];
+  const double* ref = a.xyref + (a.xy_per_map ? m : 0) * 4;
+  const double xr = ref[0], yr = ref[1];
   double th[kBeamP];
   double k[kBeamNC];
   if (tid < nch) {
@@ -178,8 +191,10 @@ __device__ __forceinline__ void beam_group_consts(const BeamArgs& a, int64_t ml,
   for (int i = 0; i < kBeamNC; ++i) L.kc[tid][i] = k[i];
   double f[kBeamNF];
   beam_fold(k, xr, yr, f);
+  if (tid < nch && !beam_form_ok(f, ref[2], ref[3])) k[11] = 1.0;   // (kc[.][11] is written below)
 #pragma unroll
   for (int i = 0; i < kBeamNF; ++i) L.fc[tid][i] = f[i];
+  L.kc[tid][11] = k[11];
 }
 
 // pixel chunk `bx` of map `ml` for the chains of group `grp` (constants in LDS): every thread's partial
@@ -190,7 +205,7 @@ __device__ __forceinline__ void beam_chunk(const BeamArgs& a, int bx, int64_t ml
   const int64_t m = a.m0 + ml;
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
-  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 2], yr = a.xyref[(a.xy_per_map ? m : 0) * 2 + 1];
+  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 4], yr = a.xyref[(a.xy_per_map ? m : 0) * 4 + 1];
   bool irregular = false, plane = false;
   for (int c = 0; c < nch; ++c) {
     irregular = irregular || L.kc[c][11] != 0.0;
@@ -287,8 +302,8 @@ __device__ __forceinline__ double beam_finish_one(int64_t e, int nchunk, const d
 // owner lanes by shuffles before the loop.
 // One wave = 16 chains of one map (chains beyond C idle: the host picks this kernel for C >= 12 of 16)
 // over a run of pixels; a lane's four sums are added over the 16 pixel columns at the end.  Exponents are
-// not clamped here: chains whose form can exceed 2^39 on the grid (exp2_tab_n's range) count as irregular,
-// and a wave with such a chain runs the exact model.
+// not clamped here: chains whose form is large on the grid (beam_form_ok) count as irregular, and a wave
+// with such a chain runs the exact model.
 typedef double beam_d4 __attribute__((ext_vector_type(4)));
 
 struct BeamMfArgs {
@@ -388,10 +403,7 @@ __global__ __launch_bounds__(256, 3) void k_beam_chi2_mf(BeamMfArgs a) {
     beam_consts(th, k);
     beam_fold(k, a.xr, a.yr, f);
   }
-  // the form's largest exponent on the grid against the table kernel's range
-  const double big = fabs(f[0]) * a.hx * a.hx + fabs(f[1]) * a.hy * a.hy + fabs(f[2]) * a.hx * a.hy +
-                     fabs(f[3]) * a.hx + fabs(f[4]) * a.hy + fabs(f[5]);
-  const bool irregular = k[11] != 0.0 || !(big < 0x1p39);
+  const bool irregular = k[11] != 0.0 || !beam_form_ok(f, a.hx, a.hy);   // (also keeps exp2_tab_n in range: no clamp here)
   const bool wave_irregular = __builtin_amdgcn_ballot_w64(irregular) != 0;
   const bool wave_plane = __builtin_amdgcn_ballot_w64(k[10] != 0.0) != 0;
   const double* dl = a.d + m * a.npix;                                 // wave-uniform

@@ -100,6 +100,8 @@ def test_beam_many_maps_on_the_matrix_cores(n, C, per_pixel_sigma):
     th[:, 0, :] = truth
     th[40, 5, 2] = np.inf                                             # one irregular wave: the exact model
     th[41, 4, 7] = 1.02                                               # mu > 1: NaN, as the reference
+    th[42, 3, 2:4] = (0.35, 0.5)                                      # a beam 1/100 of the map wide: the monomial
+    #                                                                   form would lose digits - exact model instead
     sig = noise * (1 + 0.5 * rng.random((M, n * n))) if per_pixel_sigma else noise
     with Engine() as eng:
         eng.beam_load(x, y, d, sig, center_min=prior.center_min, center_max=prior.center_max,
@@ -108,7 +110,7 @@ def test_beam_many_maps_on_the_matrix_cores(n, C, per_pixel_sigma):
         small = np.concatenate([eng.beam_lnlike(th[m0:m0 + 8], m0=m0) for m0 in range(0, M, 8)])
     assert not np.isfinite(got[40, 5]) and np.isnan(got[41, 4]) and np.isfinite(got).sum() == got.size - 2
     close(got, small, rtol=1e-12)
-    for m in (0, 40, 95):
+    for m in (0, 40, 42, 95):
         bm = RB.BeamMap(x, y, d[m], sig[m] if per_pixel_sigma else noise)
         ref = [RB.beam_lnlike(RB.beam_package(th[m, c]), bm) for c in range(C)]
         close(got[m], ref)
