@@ -11,6 +11,8 @@
 //   k_cl_form      : rows = (chain x marginalisation point); delta rows generated into LDS,
 //                    Y = delta . N^-1 on v_mfma_f64_16x16x4_f64, chi2 = rowsum(Y * delta)
 //   k_cl_combine   : log-sum-exp over the 11 (x11) grid / analytic marginalisation, -chi2/2.
+// (The header is compiled into two translation units, cl_api.hip and cl_mh_api.hip: its non-template
+// kernels are `static`, the one that does not launch them drops them.)
 #pragma once
 #include "common.hpp"
 #include "fastmath.hpp"
@@ -134,8 +136,8 @@ __device__ __forceinline__ double cl_row_value(const ClFormArgs& a, int c, int s
 constexpr int kClFormSlackRows = 32;
 #ifdef MI355_CLMH_PROF
 // phase timing of cl_form_tile (block 0, PROF builds only): staging, MFMA loop + epilogue, reduction
-__device__ long long g_clf[4];
-__device__ long long g_clf_t;
+static __device__ long long g_clf[4];
+static __device__ long long g_clf_t;
 #define CLF_TICK(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { const long long n_ = clock64(); if ((k) >= 0) g_clf[(k) & 3] += n_ - g_clf_t; g_clf_t = n_; } } while (0)
 #else
 #define CLF_TICK(k) do {} while (0)
@@ -412,12 +414,12 @@ __device__ __forceinline__ void cl_form_diag_item(const ClFormArgs& a, const int
   }
 }
 
-__global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
+static __global__ __launch_bounds__(256) void k_cl_form_diag(ClFormArgs a) {
   cl_form_diag_item(a, static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x);
 }
 
 // 1 + beam_err*ibeam*3/halfsteps for ibeam = -5..5 (ClData_CosmoMC.py:334), once per data set
-__global__ void k_cl_beam_factors(int nbp, const double* __restrict__ beam_err, double* __restrict__ bfac) {
+static __global__ void k_cl_beam_factors(int nbp, const double* __restrict__ beam_err, double* __restrict__ bfac) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= kClGrid * nbp) return;
   const int ib = e / nbp - kClHalfSteps, k = e % nbp;
@@ -508,7 +510,7 @@ __device__ __forceinline__ void cl_combine_chain(const ClCombineArgs& a, const i
   if (a.lnl) stas<IOAS>(a.lnl + c, a.accumulate ? ldas<IOAS>(a.lnl + c) + (-neg) : (0.0 + (-neg)));
 }
 
-__global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
+static __global__ __launch_bounds__(256) void k_cl_combine(ClCombineArgs a) {
   cl_combine_chain(a, static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x);
 }
 
@@ -605,7 +607,7 @@ __device__ __forceinline__ void cl_bp_tile(const double* q, int P, const double*
 }
 
 // batched path: q parameter-major [npar][n] -> bp [nbp][n]; a block of 256 threads per 16 chains
-__global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int nb, int nbp,
+static __global__ __launch_bounds__(256) void k_cl_bandpower(int64_t n, int npar, int nb, int nbp,
                                                       const double* __restrict__ q,
                                                       const double* __restrict__ K,
                                                       const int32_t* __restrict__ krange,
@@ -635,7 +637,7 @@ __device__ __forceinline__ double cl_ellnorm(int l) {     // binnedClModel.py:21
 }
 
 // K[b][i], BP0[i] of one dataset: one thread per band walks its window (set-up, runs once).
-__global__ void k_cl_build_K(ClBinning m, int nb, int nbp, int wl, const double* __restrict__ window,
+static __global__ void k_cl_build_K(ClBinning m, int nb, int nbp, int wl, const double* __restrict__ window,
                              const int32_t* __restrict__ win_min, const int32_t* __restrict__ win_max,
                              int has_pol, const uint8_t* __restrict__ inc_pol, double* K,
                              double* bp0) {
@@ -659,7 +661,7 @@ __global__ void k_cl_build_K(ClBinning m, int nb, int nbp, int wl, const double*
 }
 
 // binnedClModel.__call__ (:62-86): Cl[c][iCl][l] = (shape * q_b) * ellnorm, rows >= nCl zero.
-__global__ __launch_bounds__(256) void k_cl_model(ClBinning m, int64_t n, const double* __restrict__ q
+static __global__ __launch_bounds__(256) void k_cl_model(ClBinning m, int64_t n, const double* __restrict__ q
                                                   /*[n][npar]*/, double* __restrict__ out /*[n][3][lmax+1]*/) {
   const int L = m.lmax + 1;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(256) void k_cl_model(ClBinning m, int64_t n, const 
 
 // getWinBandpower (:422-446) for explicit spectra: one wave per (chain, band).
 // Cl host layout [n][rows][L]; rows = 1 (TT only, ndim==1 in the reference) or 3.
-__global__ __launch_bounds__(256) void k_cl_bandpower_direct(
+static __global__ __launch_bounds__(256) void k_cl_bandpower_direct(
     int64_t n, int rows, int L, const double* __restrict__ Cl, int nb, int wl,
     const double* __restrict__ window, const int32_t* __restrict__ win_min,
     const int32_t* __restrict__ win_max, int has_pol, const uint8_t* __restrict__ inc_pol,
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256) void k_cl_bandpower_direct(
 }
 
 // prior (:125-132, positive_corr): 0 if any auto-spectrum bin is negative
-__global__ void k_cl_prior(int64_t n, int npar, const int32_t* __restrict__ cltype,
+static __global__ void k_cl_prior(int64_t n, int npar, const int32_t* __restrict__ cltype,
                            const double* __restrict__ q /*[n][npar]*/, double* __restrict__ prior) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= n) return;
@@ -715,7 +717,7 @@ __global__ void k_cl_prior(int64_t n, int npar, const int32_t* __restrict__ clty
 }
 
 // getdelta (:377-398) of explicit band-power vectors: BP host layout [n][nb] -> delta [n][nb]
-__global__ void k_cl_delta(int64_t n, int nb, const double* __restrict__ BP,
+static __global__ void k_cl_delta(int64_t n, int nb, const double* __restrict__ BP,
                            const double* __restrict__ obs, const double* __restrict__ xf,
                            const uint8_t* __restrict__ hasx, int has_x, double* __restrict__ out) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -732,7 +734,7 @@ __global__ void k_cl_delta(int64_t n, int nb, const double* __restrict__ BP,
 }
 
 // getlinform (:407-412): out[c][i] = sum_k N^-1[i][k] vec[c][k]  (or vec/var)
-__global__ __launch_bounds__(256) void k_cl_linform(int64_t n, int nb, int nbp,
+static __global__ __launch_bounds__(256) void k_cl_linform(int64_t n, int nb, int nbp,
                                                     const double* __restrict__ vec,
                                                     const double* __restrict__ ninv,
                                                     const double* __restrict__ var,
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(256) void k_cl_linform(int64_t n, int nb, int nbp,
 }
 
 // [n][cols] -> [colsp][n] with zero padding rows
-__global__ void k_cl_to_bandmajor(int64_t n, int cols, int colsp, const double* __restrict__ in,
+static __global__ void k_cl_to_bandmajor(int64_t n, int cols, int colsp, const double* __restrict__ in,
                                   double* __restrict__ out) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= n * colsp) return;

@@ -126,7 +126,7 @@ static void sync_block_masks(mi355_ctx* c) {
 static int fused_kind(mi355_ctx* c) {
   GmhState* g = c->gmh;
   if (!c->mh_fused) return 0;
-  if (g->pb.kind == GMH_CL && cl_mh_fused_nw(c, g->pb.P, c->nblock, c->npn) > 0) return 1;
+  if (g->pb.kind == GMH_CL && cl_mh_fused_nw(c, g->pb.P, c->nblock, c->npn, g->cov_on ? 1 : 0) > 0) return 1;
   if (g->pb.kind == GMH_SED && sed_mh_fused_ok(c)) return 2;
   return 0;
 }

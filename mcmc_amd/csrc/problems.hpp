@@ -8,13 +8,14 @@ namespace mi355 {
 
 // binnedCl: number of parameters and the spectrum type of each (device array), cl_api.hip
 int cl_problem_info(const mi355_ctx* c, int* npar, const int32_t** cltype_dev);
-// binnedCl: the fused Metropolis-Hastings kernel (cl_mh_kernels.hpp).  cl_mh_fused_nw: waves per
-// block of the instantiation that serves the loaded problem, 0 if the problem needs the step-wise
-// engine (more than 11 marginalisation points per chain, too many data sets, LDS).  cl_mh_run:
+// binnedCl: the fused Metropolis-Hastings kernels (cl_mh_kernels.hpp, cl_mhw_kernels.hpp; host side in
+// cl_mh_api.hip).  cl_mh_fused_nw: > 0 if one of them serves the loaded problem and the job of the context
+// (its chain count, `comom`: running co-moments), 0 if it needs the step-wise engine (too many data sets or
+// parameters, LDS, an 11 x 11 grid on very many chains).  cl_mh_run:
 // nsteps steps of every chain in one launch on the context stream; `a` carries the chain state,
 // the counters of the first step and, as bases of the whole run, the injected draws and the trace.
 struct GmhArgs;
-int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn);
+int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn, int comom);
 int cl_mh_run(mi355_ctx* c, const GmhArgs& a, int64_t nsteps, int thin, int64_t nkeep);
 // BeamFit: number of maps and the prior box, beam_api.hip
 int beam_problem_info(const mi355_ctx* c, int64_t* M, BeamPriorBox* box);
