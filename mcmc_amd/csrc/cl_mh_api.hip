@@ -97,6 +97,11 @@ static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int
   // at 2048 chains, 197 / 259 at 4096, 434 / 473 at 8192, 915 / 803 at 16 384).  The 11-point grids stay
   // fused at every size (25 / 56 us at 4096 chains, 73 / 133 at 16 384, 258 / 364 at 65 536).
   if (mode != 1 && f.rows_per_chain > kClGrid && tiles > 2 * kCUs) return r;
+  // With the running co-moments (every adaptive stage of sampler()): this kernel updates them in memory every
+  // step, P (P + 1) / 2 entries per chain, where the block kernel keeps them in registers (its resident
+  // instantiations) - us per step with 32 parameters, wave / block / step-wise: 58 / 45 / 87 at 16 384 chains,
+  // 63 / 46 / 93 with the 11-point grid at 4096 chains, 155 / 172 / 243 at 65 536 chains (both in memory there).
+  if (mode != 1 && comom && tiles <= 8 * kCUs && cl_mh_block_ok(p, P, nblock, npn)) return r;
   r.ms = kClMhwSlots;
   r.nct_t = nct <= 4 ? 4 : 8;
   r.sym = nct >= 8 ? 1 : 0;
