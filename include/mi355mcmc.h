@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 2
+#define MI355_ABI_VERSION 3
 
 typedef struct mi355_ctx mi355_ctx;
 

@@ -10,7 +10,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355MCMC_LIB") or os.path.join(_HERE, "libmi355mcmc.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
