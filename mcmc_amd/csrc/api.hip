@@ -135,16 +135,17 @@ struct LaunchStart {
   }
 };
 
-// Every source of the catalogue is in the domain of the clamp-free kernels (the (chain, band) lane
-// mapping needs that; the plain, extended and incremental samplers split a mixed catalogue into two
-// launches over disjoint lists of chain blocks).
+// Every source of the catalogue is in the domain of the clamp-free kernels (otherwise the plain,
+// extended and incremental samplers - and the (chain, band) lane mapping of the first two - split a
+// mixed catalogue into two launches over disjoint lists of chain blocks).
 static bool sed_all_fast(const mi355_ctx* c) { return c->kc.fast_ok != 0.0 && c->nslow == 0; }
 
 // Block size and lanes per chain of the next k_mh_run launch (ext: its extended instantiation, which
 // keeps a sqrt matrix per lane in LDS).  Lanes per chain: 1 = lane per chain; 8 / 32 = lanes (chain,
-// band), picked when the whole catalogue is on the fast path and the job is too small to give every
-// SIMD of the GPU a wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has the
-// crossover there, 3x (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
+// band), picked when the catalogue has sources on the fast path (the chain blocks of the others then
+// run lane = chain beside them: LaunchRun) and the job is too small to give every SIMD of the GPU a
+// wave of chains (1024 SIMDs x 64 lanes): tools/ubench_lanemap.hip has the crossover there, 3x
+// (nb = 27) / 1.6x (nb = 8) below it and a loss of 3x above.
 // mi355_mh_set_lane_map overrides (tests hold the two mappings to identical chains).  The block is
 // the largest of 256 / 128 / 64 lanes whose band tables, per-lane extras and exchange slots fit.
 struct SedPlan {
@@ -164,7 +165,7 @@ static SedPlan sed_plan(const mi355_ctx* c, bool ext) {
   SedPlan p;
   const size_t per_lane = ext ? static_cast<size_t>(c->P * (c->P + 1) / 2) * sizeof(double) : 0;
   p.bs = pick_block_x(c, per_lane, 0, &p.lds);
-  if (c->lane_map == 1 || !sed_all_fast(c) || c->model.model == MI355_SED_M2) return p;
+  if (c->lane_map == 1 || c->kc.fast_ok == 0.0 || c->nslow >= c->S || c->model.model == MI355_SED_M2) return p;
   const int g = c->nb_most <= 8 ? 8 : (c->nb_most <= 32 ? 32 : 0);
   if (g == 0 || c->nb_most < 2) return p;
   if (c->lane_map != 2 && c->N * g > 65536) return p;
@@ -178,7 +179,8 @@ static SedPlan sed_plan(const mi355_ctx* c, bool ext) {
   return p;
 }
 
-// Lists of the chain blocks (bs chains each) whose sources are all fast / not all fast.
+// Lists of the chain blocks (bs chains each: the kernel's lanes per block over its lanes per chain) whose
+// sources are all fast / not all fast.
 static int build_block_lists(mi355_ctx* c, int bs) {
   if (c->blk_bs == bs && c->blk_C == c->C) return 0;
   const int64_t nblk = ceil_div(c->N, bs);
@@ -269,25 +271,44 @@ struct LaunchRun {
       MI355_REQUIRE(pe.bs > 0, "the extended fused sampler does not serve this catalogue (step-wise engine only)");
       const unsigned grid_e = static_cast<unsigned>(ceil_div(c->N, pe.bs / pe.G));
       if (!sed_all_fast(c)) {
-        // sources outside the fast domain (sed_plan keeps lane = chain then): the per-lane instantiation
-        // for the whole grid, or - mixed catalogue - for the blocks that hold such a source, beside the
+        // sources outside the fast domain: the per-lane instantiation for the whole grid (sed_plan keeps
+        // lane = chain then), or - mixed catalogue - for the blocks that hold such a source, beside the
         // fast instantiation for all the others, as the plain sampler below
         if (c->kc.fast_ok == 0.0) {
           if (launch_lds((k_mh_run<M, false, true>), grid_e, pe.bs, pe.lds, c->stream, a)) return -2;
         } else {
-          if (build_block_lists(c, pe.bs)) return -2;
+          // (a small job: both kernels with lanes = (chain, band), the exact path band-parallel as well)
+          if (build_block_lists(c, pe.bs / pe.G)) return -2;
           MhArgs af = a, as = a;
           af.blocklist = c->blk_fast.p;
           as.blocklist = c->blk_slow.p;
           MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
           MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-          if (launch_lds((k_mh_run<M, false, true>), static_cast<unsigned>(c->nblk_slow), pe.bs, pe.lds, c->stream2, as))
-            return -2;
+          const unsigned gs = static_cast<unsigned>(c->nblk_slow);
+          if constexpr (M != MI355_SED_M2) {
+            if (pe.G == 8)
+              { if (launch_lds((k_mh_run<M, false, true, 8>), gs, pe.bs, pe.lds, c->stream2, as)) return -2; }
+            else if (pe.G == 32)
+              { if (launch_lds((k_mh_run<M, false, true, 32>), gs, pe.bs, pe.lds, c->stream2, as)) return -2; }
+            else
+              { if (launch_lds((k_mh_run<M, false, true>), gs, pe.bs, pe.lds, c->stream2, as)) return -2; }
+          } else {
+            { if (launch_lds((k_mh_run<M, false, true>), gs, pe.bs, pe.lds, c->stream2, as)) return -2; }
+          }
           MI355_HIP(hipGetLastError());
           MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
           if (c->nblk_fast > 0) {
-            if (launch_lds((k_mh_run<M, true, true>), static_cast<unsigned>(c->nblk_fast), pe.bs, pe.lds, c->stream, af))
-              return -2;
+            const unsigned gf = static_cast<unsigned>(c->nblk_fast);
+            if constexpr (M != MI355_SED_M2) {
+              if (pe.G == 8)
+                { if (launch_lds((k_mh_run<M, true, true, 8>), gf, pe.bs, pe.lds, c->stream, af)) return -2; }
+              else if (pe.G == 32)
+                { if (launch_lds((k_mh_run<M, true, true, 32>), gf, pe.bs, pe.lds, c->stream, af)) return -2; }
+              else
+                { if (launch_lds((k_mh_run<M, true, true>), gf, pe.bs, pe.lds, c->stream, af)) return -2; }
+            } else {
+              { if (launch_lds((k_mh_run<M, true, true>), gf, pe.bs, pe.lds, c->stream, af)) return -2; }
+            }
           }
           MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
@@ -334,20 +355,47 @@ struct LaunchRun {
     else {
       // mixed catalogue: the blocks with a source outside the fast domain on stream2 (each lane
       // follows its own source there), all the others through the fast instantiation beside them
-      if (build_block_lists(c, bs)) return -2;
+      // (a small job: both kernels with lanes = (chain, band), the exact path band-parallel as well)
+      const SedPlan pp = sed_plan(c, false);
+      if (build_block_lists(c, pp.G > 1 ? pp.bs / pp.G : bs)) return -2;
       MhArgs af = a, as = a;
       af.blocklist = c->blk_fast.p;
       as.blocklist = c->blk_slow.p;
       MI355_HIP(hipEventRecord(c->ev_fork, c->stream));
       MI355_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-      { if (launch_lds((k_mh_run<M, false>), static_cast<unsigned>(c->nblk_slow), bs, lds, c->stream2, as)) return -2; }
+      const unsigned gs = static_cast<unsigned>(c->nblk_slow);
+      bool slow_done = false;
+      if constexpr (M != MI355_SED_M2) {
+        slow_done = pp.G > 1;
+        if (pp.G == 8)
+          { if (launch_lds((k_mh_run<M, false, false, 8>), gs, pp.bs, pp.lds, c->stream2, as)) return -2; }
+        else if (pp.G == 32)
+          { if (launch_lds((k_mh_run<M, false, false, 32>), gs, pp.bs, pp.lds, c->stream2, as)) return -2; }
+      }
+      if (!slow_done)
+        { if (launch_lds((k_mh_run<M, false>), gs, bs, lds, c->stream2, as)) return -2; }
       MI355_HIP(hipGetLastError());
       MI355_HIP(hipEventRecord(c->ev_join, c->stream2));
       if (c->nblk_fast > 0) {
-        if (single_blocks(c))
-          { if (launch_lds((k_mh_run<M, true, false, 1, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
+        const unsigned gf = static_cast<unsigned>(c->nblk_fast);
+        bool done = false;
+        if constexpr (M != MI355_SED_M2) {
+          done = pp.G > 1;
+          if (pp.G == 8 && single_blocks(c))
+            { if (launch_lds((k_mh_run<M, true, false, 8, true>), gf, pp.bs, pp.lds, c->stream, af)) return -2; }
+          else if (pp.G == 32 && single_blocks(c))
+            { if (launch_lds((k_mh_run<M, true, false, 32, true>), gf, pp.bs, pp.lds, c->stream, af)) return -2; }
+          else if (pp.G == 8)
+            { if (launch_lds((k_mh_run<M, true, false, 8>), gf, pp.bs, pp.lds, c->stream, af)) return -2; }
+          else if (pp.G == 32)
+            { if (launch_lds((k_mh_run<M, true, false, 32>), gf, pp.bs, pp.lds, c->stream, af)) return -2; }
+        }
+        if (done)
+          ;
+        else if (single_blocks(c))
+          { if (launch_lds((k_mh_run<M, true, false, 1, true>), gf, bs, lds, c->stream, af)) return -2; }
         else
-          { if (launch_lds((k_mh_run<M, true>), static_cast<unsigned>(c->nblk_fast), bs, lds, c->stream, af)) return -2; }
+          { if (launch_lds((k_mh_run<M, true>), gf, bs, lds, c->stream, af)) return -2; }
       }
       MI355_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }

@@ -167,7 +167,7 @@ struct mi355_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   mi355::DevBuf<int32_t> blk_fast, blk_slow;
   int64_t nblk_fast = 0, nblk_slow = 0;
-  int blk_bs = 0, blk_C = 0;      // the (block size, chains per source) the lists were built for
+  int blk_bs = 0, blk_C = 0;      // the (chains per block, chains per source) the lists were built for
 
   // --- chain state (N = S*C chains, parameter-major so lanes coalesce) --------------
   bool mh_ready = false;

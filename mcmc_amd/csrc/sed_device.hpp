@@ -685,6 +685,80 @@ __device__ void sed_flux(const double* th, double nu, const SedConsts& k, double
   }
 }
 
+// The exact path for a chain that owns G lanes (a source outside the fast domain in a job small enough
+// for the (chain, band) mapping): lane jb evaluates band jb through the formulas of sed_lnlike, then
+// every lane of the group adds the band terms in band order with the one-lane loop's own multiply and
+// add - the same value bit for bit.  SEDLikelihood2 stays lane = chain (the host never picks G > 1).
+template <int MODEL, int G>
+__device__ __forceinline__ double sed_lnlike_exact_cb(const double* th, const Bands& B, const SedConsts& k,
+                                                      int jb, double2* slot) {
+  static_assert(MODEL != MI355_SED_M2, "SEDLikelihood2: lane = chain");
+  const bool mine = jb < B.nb;
+  const double2* grp = slot - jb;
+  if constexpr (MODEL == MI355_SED_M1) {
+    const double beta = th[0], T = th[1];
+    const double pre = k.prefac * pow(k.nu_b, -beta);
+    const double e3 = 3.0 + beta;
+    double g = 0.0, gw = 0.0;
+    if (mine) {
+      g = pre * pow(B.nu(jb), e3) / expm1(B.hnu(jb) / T);
+      gw = g * B.w(jb);
+    }
+    cb_publish(slot, gw, g);
+    double FNiF = 0.0, FNid = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double2 v = grp[j];
+      FNiF += v.x * v.y;
+      FNid += v.x * B.d(j);
+    }
+    const double amp = FNid / FNiF;
+    return 0.5 * FNid * amp;
+  } else {
+    double r = 0.0, rw = 0.0;
+    if constexpr (MODEL == MI355_SED_M1N || MODEL == MI355_SED_M1N_LOGA || MODEL == MI355_SED_THICK_LOGA) {
+      const double A = (MODEL == MI355_SED_M1N) ? th[0] : pow(10.0, th[0]);
+      const double T = th[2], e3 = 3.0 + th[1];
+      const double en = expm1(k.hk_nub / T);
+      if (mine) {
+        const double g = pow(B.ratio(jb), e3) * en / expm1(B.hnu(jb) / T);
+        r = B.d(jb) - A * g;
+      }
+    } else if constexpr (MODEL == MI355_SED_M2N || MODEL == MI355_SED_M2N_LOGA) {
+      const bool lg = (MODEL == MI355_SED_M2N_LOGA);
+      const double A1 = lg ? pow(10.0, th[0]) : th[0];
+      const double A2 = lg ? pow(10.0, th[3]) : th[3];
+      const double T1 = th[2], T2 = th[5];
+      const double e1 = 3.0 + th[1], e2 = 3.0 + th[4];
+      const double en1 = expm1(k.hk_nub / T1), en2 = expm1(k.hk_nub / T2);
+      if (mine) {
+        const double hn = B.hnu(jb), rt = B.ratio(jb);
+        const double g1 = pow(rt, e1) * en1 / expm1(hn / T1);
+        const double g2 = pow(rt, e2) * en2 / expm1(hn / T2);
+        r = B.d(jb) - (A1 * g1 + A2 * g2);
+      }
+    } else {                                               // MI355_SED_THICK
+      const double A = th[0], b = th[1], T = th[2], nu0 = th[3];
+      const double en = expm1(k.hk_nub / T);
+      const double tau_b = pow(k.nu_b / nu0 / k.nu_rescale, b);
+      const double den = 1.0 - exp(-tau_b);
+      if (mine) {
+        const double tau = pow(B.nu(jb) / nu0 / k.nu_rescale, b);
+        const double bb = pow(B.ratio(jb), 3.0) * en / expm1(B.hnu(jb) / T);
+        const double m = A * (1.0 - exp(-tau)) / den * bb;
+        r = B.d(jb) - m;
+      }
+    }
+    if (mine) rw = r * B.w(jb);
+    cb_publish(slot, rw, r);
+    double chi2 = 0.0;
+    for (int j = 0; j < B.nb; ++j) {
+      const double2 v = grp[j];
+      chi2 += v.x * v.y;
+    }
+    return -0.5 * chi2;
+  }
+}
+
 // What every caller uses: the fast path where it is valid, the exact path elsewhere.
 template <int MODEL>
 __device__ __forceinline__ double sed_lnlike_auto(const double* th, double prior, const Bands& B,

@@ -299,7 +299,7 @@ constexpr int mh_min_waves() {
 // instruction count); one block of 768 lanes per CU (48 ms, average occupancy 2.2 waves per SIMD).
 template <int MODEL, bool FAST, bool EXT = false, int G = 1, bool SINGLE = false, int XM = -1>
 __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>())) void k_mh_run(MhArgs a) {
-  static_assert(G == 1 || FAST, "(chain, band) lanes: fast path only");
+  static_assert(G == 1 || MODEL != MI355_SED_M2, "(chain, band) lanes: not for SEDLikelihood2");
   static_assert(!SINGLE || !EXT, "single-parameter blocks: plain sampler");
   static_assert(XM == -1 || ((XM == 1 || XM == 2) && EXT && G == 1), "XM: the Cholesky-correlated extended sampler, lane = chain");
   // XM = 2: XM = 1 with the running co-moments in registers for the launch (loaded before the first
@@ -581,7 +581,9 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
     // rejected below like any bad likelihood, so the fast instantiation needs no finiteness test.
     if (prior > 0.0 && (FAST || all_finite<P>(nw))) {
       double v;
-      if constexpr (G > 1) v = sed_lnlike_fast_cb<MODEL, G>(nw, B, a.k, jb, cb_slot);
+      if constexpr (G > 1 && FAST) v = sed_lnlike_fast_cb<MODEL, G>(nw, B, a.k, jb, cb_slot);
+      else if constexpr (G > 1) v = B.fast ? sed_lnlike_fast_cb<MODEL, G>(nw, B, a.k, jb, cb_slot)
+                                           : sed_lnlike_exact_cb<MODEL, G>(nw, B, a.k, jb, cb_slot);
       else v = (FAST || B.fast) ? sed_lnlike_fast<MODEL>(nw, B, a.k, nullptr)
                                 : sed_lnlike<MODEL>(nw, B, a.k, nullptr);
       const bool bad = (v != v) || (v == -__builtin_inf());   // MCMC.py:238-243

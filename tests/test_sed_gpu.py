@@ -522,6 +522,55 @@ def test_mixed_catalogue_splits_source_by_source(mid, C):
         np.testing.assert_allclose(lp[:, s, c], np.asarray(ch.lnPr)[1:], rtol=1e-11)
 
 
+@pytest.mark.parametrize("mid,nbands,G,C", [(R.M2N, 8, 8, 16), (R.M1N, 27, 32, 5), (R.THICK, 8, 8, 100)])
+@pytest.mark.parametrize("ext", [False, True])
+def test_lane_mappings_split_a_mixed_catalogue_alike(mid, nbands, G, C, ext):
+    """A small job with a radio point under lanes = (chain, band): the chain blocks that hold such a source
+    run the exact formulas band-parallel too (each lane its band, the terms added in band order), all the
+    others keep the fast band-parallel kernel beside them - the same chains, bit for bit, as forced lane =
+    chain gives on the same catalogue (which test_mixed_catalogue_splits_source_by_source pins to the
+    oracle); plain and extended sampler."""
+    from mcmc_amd import Engine
+    S, nsteps = 41, 50
+    P = R.MODEL_NPARAM[mid]
+    nu, d, sig, truth = R.synth_sed_catalogue(S, seed=31, nb=nbands)
+    nu[[2, 17, 40], 0] = 1.4
+    nb = np.full(S, nbands, np.int32)
+    nb[5] = nbands - 1
+    th0 = _start_point(mid, truth)
+    rng = np.random.default_rng(8)
+    A = rng.normal(size=(P, P))
+    cov = A @ A.T + P * np.eye(P)
+    dg = np.sqrt(np.diag(cov))
+    L = np.linalg.cholesky(cov / dg[:, None] / dg[None, :])
+    out = {}
+    for lane_map in (1, 2):
+        with Engine(seed=11) as e:
+            e.mh_set_lane_map(lane_map)
+            e.sed_load(mid, nb, nu, d, sig)
+            assert e.sed_fast_sources == S - 3
+            start = th0[:, None, :].repeat(C, axis=1)
+            if ext:
+                e.mh_init_problem("sed", C, start, np.full(P, 0.02), param_blocks=np.arange(P),
+                                  randomize_start=False, track_cov=True)
+                e.mh_set_sqrt_matrix(L)
+                assert e.mh_fused_active
+            else:
+                e.mh_init(C, start, np.full(P, 0.02), param_blocks=np.arange(P), randomize_start=False)
+                assert e.mh_lane_group == (G if lane_map == 2 else 1)
+            e.mh_run(nsteps, thin=1)
+            tr = e.mh_trace()
+            e.mh_run(21)
+            out[lane_map] = (tr, e.mh_moments(), e.mh_covar(normalized=False) if ext else ())
+    for x, y in zip(out[1][0], out[2][0]):
+        assert np.array_equal(x, y, equal_nan=True)
+    for k in out[1][1]:
+        assert np.array_equal(out[1][1][k], out[2][1][k], equal_nan=True), k
+    for x, y in zip(out[1][2], out[2][2]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert out[1][0][2].mean() > 0.05
+
+
 def _start_point(mid, truth):
     P = R.MODEL_NPARAM[mid]
     if mid == R.M1:
@@ -635,12 +684,16 @@ def test_lane_mapping_is_picked_by_job_size():
         assert e.mh_lane_group == 1                       # 19 200 chains x 8 lanes > 65 536
         e.sed_load(R.M2, nb[:4], nu[:4], d[:4], sig[:4])
         e.mh_init(16, truth[0, [1, 2, 4, 5]], np.full(4, 0.02), param_blocks=np.arange(4))
-        assert e.mh_lane_group == 1                       # SEDLikelihood2 has no fast path
+        assert e.mh_lane_group == 1                       # SEDLikelihood2: lane = chain only
         nu2 = nu[:4].copy()
         nu2[2, 0] = 1.4
         e.sed_load(R.M2N, nb[:4], nu2, d[:4], sig[:4])
         e.mh_init(16, truth[0], np.full(6, 0.02), param_blocks=np.arange(6))
-        assert e.mh_lane_group == 1                       # a source on the exact path
+        assert e.mh_lane_group == 8                       # a source on the exact path: its block of chains runs lane = chain beside
+        nu2[:, 0] = 1.4
+        e.sed_load(R.M2N, nb[:4], nu2, d[:4], sig[:4])
+        e.mh_init(16, truth[0], np.full(6, 0.02), param_blocks=np.arange(6))
+        assert e.mh_lane_group == 1                       # every source on the exact path
 
 
 def test_sed_abi_errors_leave_the_context_usable():
