@@ -163,8 +163,9 @@ int mi355_mh_incremental_active(mi355_ctx* ctx);
  * step from nb band evaluations to one and is what a small job wants (one source, a handful of
  * chains: the reference's own use).  mode 0 (default): (chain, band) when chains x G <= 65 536 lanes
  * (one wave per SIMD of the GPU), lane = chain beyond; 1 / 2 force either.  The chains are the same
- * bit for bit under both mappings.  (chain, band) applies to uncorrelated proposals on a catalogue
- * that is wholly on the fast path with at most 32 bands per source (not SEDLikelihood2);
+ * bit for bit under both mappings.  (chain, band) applies to catalogues with at most 32 bands per
+ * source and at least one source on the fast path (not SEDLikelihood2; the chain blocks of sources
+ * outside the fast domain run the exact formulas band-parallel beside the others);
  * mi355_mh_lane_group: the G the next mi355_mh_run of this context would use (1, 8 or 32). */
 int mi355_mh_set_lane_map(mi355_ctx* ctx, int32_t mode);
 int mi355_mh_lane_group(mi355_ctx* ctx);
@@ -343,7 +344,9 @@ int mi355_mh_init_problem(mi355_ctx* ctx, int32_t problem, int32_t C, const doub
  * fast-path check of mi355_sed_load runs in the fused SED kernel of mi355_mh_init, extended by the
  * correlated and rotated proposals (Proposal.py:145-154) and the co-moments.  Same draws, same
  * arithmetic, same chains as the step-wise launches, bit for bit.  on=0 forces the step-wise
- * launches (on by default).
+ * launches; on=1 (default) takes the one-launch path where it is the faster one (the full 11 x 11 grid
+ * runs fused between 2049 and 8192 chains and step-wise outside); on=2 takes it wherever a fused kernel
+ * serves the problem.
  * mi355_mh_fused_active: 1 if the next mi355_mh_run of this context takes the one-launch path. */
 int mi355_mh_set_fused(mi355_ctx* ctx, int32_t on);
 int mi355_mh_fused_active(mi355_ctx* ctx);

@@ -76,10 +76,12 @@ struct ClMhwPlan {
   size_t lds = 0;
 };
 static bool cl_mh_block_ok(const ClProblem* p, int P, int nblock, int npn);   // k_cl_mh_run serves the problem
-static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int64_t N, int comom = 1) {
+static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int64_t N, int comom = 1, bool force = false) {
   ClMhwPlan r;
-  static const int mode = [] { const char* e = getenv("MI355_CLMH_WAVE"); return e ? atoi(e) : -1; }();
-  if (mode == 0 || !p->mh_filled || p->data.size() != 1) return r;   // (MI355_CLMH_WAVE: 0 never, 1 wherever it applies)
+  static const int env = [] { const char* e = getenv("MI355_CLMH_WAVE"); return e ? atoi(e) : -1; }();
+  if (env == 0 || !p->mh_filled || p->data.size() != 1) return r;   // (MI355_CLMH_WAVE: 0 never, 1 wherever it applies)
+  // (force: mi355_mh_set_fused(ctx, 2) - the 121-point grid through this kernel whatever the job size)
+  const int mode = (env == 1) ? 1 : -1;
   const ClData* d = p->data[0].get();
   const FormPlan f = plan_for(d);
   const int nct = d->nbp >> 4;
@@ -96,12 +98,14 @@ static ClMhwPlan cl_mhw_plan(const ClProblem* p, int P, int nblock, int npn, int
   // step engine's form kernel is the faster one from there (per step, fused against step-wise: 188 / 197 us
   // at 2048 chains, 197 / 259 at 4096, 434 / 473 at 8192, 915 / 803 at 16 384).  The 11-point grids stay
   // fused at every size (25 / 56 us at 4096 chains, 73 / 133 at 16 384, 258 / 364 at 65 536).
-  if (mode != 1 && f.rows_per_chain > kClGrid && tiles > 2 * kCUs) return r;
-  // With the running co-moments (every adaptive stage of sampler()): this kernel updates them in memory every
-  // step, P (P + 1) / 2 entries per chain, where the block kernel keeps them in registers (its resident
-  // instantiations) - us per step with 32 parameters, wave / block / step-wise: 58 / 45 / 87 at 16 384 chains,
-  // 63 / 46 / 93 with the 11-point grid at 4096 chains, 155 / 172 / 243 at 65 536 chains (both in memory there).
-  if (mode != 1 && comom && tiles <= 8 * kCUs && cl_mh_block_ok(p, P, nblock, npn)) return r;
+  // Below 4096 chains the eight replica waves of a 16-chain tile - one block, one CU - walk 15 forms each
+  // on as many CUs as the job has tiles, where the batched form kernel spreads chains x 121 rows over the chip:
+  // 188 / 116 us at 512 chains, 189 / 137 at 1024, 191 / 188 at 2048 (with co-moments 222 / 113 ... 223 / 189).
+  if (mode != 1 && !force && f.rows_per_chain > kClGrid && (tiles > 2 * kCUs || tiles <= kCUs / 2)) return r;
+  // (The running co-moments - every adaptive stage of sampler() - are updated in memory by this kernel, in
+  // registers by the block kernel's resident instantiations: gmh_comom_update.  us per step with 32 parameters,
+  // wave / block: 24.5 / 24.8 at 8192 chains, 42.8 / 41.0 at 16 384, 56 / 61 at 24 576, 65 / 80 at 32 768;
+  // 11-point grid 30 / 46 at 4096 chains, 86 / 130 at 16 384: no rule of their own.)
   r.ms = kClMhwSlots;
   r.nct_t = nct <= 4 ? 4 : 8;
   r.sym = nct >= 8 ? 1 : 0;
@@ -177,7 +181,7 @@ static bool cl_mh_block_ok(const ClProblem* p, int P, int nblock, int npn) {
 int cl_mh_fused_nw(const mi355_ctx* c, int P, int nblock, int npn, int comom) {
   if (!c || !c->cl || !c->cl->binned) return 0;
   // (the wave-per-16-chains kernel: its policy depends on the number of chains of the job)
-  if (cl_mhw_plan(c->cl, P, nblock, npn, c->N > 0 ? c->N : int64_t{1} << 30, comom).ok) return 1;
+  if (cl_mhw_plan(c->cl, P, nblock, npn, c->N > 0 ? c->N : int64_t{1} << 30, comom, c->mh_fused == 2).ok) return 1;
   return cl_mh_block_ok(c->cl, P, nblock, npn) ? c->cl->mh_nw : 0;
 }
 
@@ -282,7 +286,7 @@ int cl_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t 
   ClProblem* p = c->cl;
   const int nw = cl_mh_fused_nw(c, g.pb.P, g.nblock, g.npn, g.comom != nullptr);
   MI355_REQUIRE(nw > 0, "cl_mh_run: the loaded Cl problem has no fused kernel");
-  const ClMhwPlan wplan = cl_mhw_plan(p, g.pb.P, g.nblock, g.npn, g.N, g.comom != nullptr);
+  const ClMhwPlan wplan = cl_mhw_plan(p, g.pb.P, g.nblock, g.npn, g.N, g.comom != nullptr, c->mh_fused == 2);
   if (wplan.ok) {
     ClMhArgs a{};
     a.g = g;

@@ -576,30 +576,9 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
     }
     if (g.comom != nullptr) {                              // uniform over the grid
       cl_mhw_sync();
-      if (valid && writer) {
-        // C_ij += (n-1)/n d_i d_j, lower triangle dealt round-robin to the chain's lanes (k_gmh_accept)
-        const int T = P * (P + 1) / 2;
-        constexpr int U = 8;
-        for (int e0 = grp; e0 < T; e0 += G * U) {
-          double* ptr[U];
-          double inc[U], cur[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * G;
-            ptr[u] = nullptr;
-            if (e < T) {
-              int i, j;
-              gmh_tri_decode(e, i, j);
-              ptr[u] = g.comom + (static_cast<int64_t>(i) * P + j) * N + n;
-              inc[u] = cf * dl[i * CB + cl] * dl[j * CB + cl];
-              cur[u] = ldas<1>(ptr[u]);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (ptr[u]) stas<1>(ptr[u], cur[u] + inc[u]);
-        }
-      }
+      // C_ij += (n-1)/n d_i d_j (k_gmh_accept), the columns dealt round-robin to the chain's lanes and - every
+      // replica holds the same x - mean - to the replicas
+      if (valid) gmh_comom_update(g.comom, N, n, P, cf, dl + cl, CB, grp + G * rid, G * rep);
       cl_mhw_sync();                                       // dl is rewritten by the next step
     }
     if (g.nblock) blk = (blk + 1 == g.nblock) ? 0 : blk + 1;   // MCMC.py:278-279

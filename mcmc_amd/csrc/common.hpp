@@ -128,6 +128,27 @@ __device__ __forceinline__ void stas(T* p, T v) {
   else *p = v;
 }
 
+// *p += v in global memory without waiting for *p: one global_atomic_add_f64 with no return value.  The add
+// unit of L2 rounds like the vector ALU, and the adds a lane sends to one address are applied in program
+// order, so a running sum kept this way equals the load / add / store sequence bit for bit - while the lane
+// goes on instead of sitting out a memory round trip per batch of entries (the running co-moments:
+// P (P + 1) / 2 entries per chain and step).  Only for memory no other lane touches during the launch.
+// (Through a global-address-space pointer: the flat form of the instruction also counts as an LDS operation,
+// and the lane's next LDS read would wait for it.)
+__device__ __forceinline__ void add_noret(double* p, double v) {
+  typedef __attribute__((address_space(1))) double gdouble;
+  [[clang::atomic(ignore_denormal_mode, no_fine_grained_memory, no_remote_memory)]] {
+    (void)__hip_atomic_fetch_add((gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Co-moment entries of one step (chains x P (P + 1) / 2) up to which the running co-moments are kept with
+// add_noret; beyond, with loads and stores (gmh_comom_update in gmh_device.hpp has the measurements).
+#ifndef MI355_COMOM_ATOMIC_MAX
+#define MI355_COMOM_ATOMIC_MAX (int64_t{1} << 23)
+#endif
+constexpr int64_t kComomAtomicMaxEntries = MI355_COMOM_ATOMIC_MAX;
+
 struct SedConsts {
   double h_over_k, nu_b, prefac, Tmin, Tmax, bmin, bmax, nu_rescale;
   double hk_nub;   // h_over_k * nu_b, rounded once like model.py:91,108
@@ -181,7 +202,7 @@ struct mi355_ctx {
   int npn = 1;                    // normals drawn per step in free-running mode
   bool incremental = false;       // mi355_mh_set_incremental: k_mh_run_inc where it applies
   int lane_map = 0;               // mi355_mh_set_lane_map: 0 automatic, 1 lane = chain, 2 lanes = (chain, band)
-  bool mh_fused = true;           // mi355_mh_set_fused: step-wise problems run their fused kernel where one exists
+  int mh_fused = 1;               // mi355_mh_set_fused: step-wise problems run their fused kernel where one exists (2: whatever the job size)
   int64_t step_total = 0;         // Philox stream position (never reset)
   int64_t stage_step = 0;         // steps since the last init/adapt (iBlock = stage_step % nblock)
   int64_t stage = 0;              // number of init/adapt calls (keys the start stream)

@@ -617,7 +617,8 @@ int mi355_mh_track_cov(mi355_ctx* c, int32_t on) {
 
 int mi355_mh_set_fused(mi355_ctx* c, int32_t on) {
   MI355_REQUIRE(c, "null context");
-  c->mh_fused = on != 0;
+  MI355_REQUIRE(on >= 0 && on <= 2, "mi355_mh_set_fused: %d (0 step-wise, 1 fused where it is the faster path, 2 fused wherever a kernel serves)", on);
+  c->mh_fused = on;
   return 0;
 }
 

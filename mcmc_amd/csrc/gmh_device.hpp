@@ -184,6 +184,60 @@ __device__ __forceinline__ void gmh_tri_decode(int e, int& i, int& j) {
   j = e - i * (i + 1) / 2;
 }
 
+// C_ij += (n-1)/n d_i d_j, j <= i (MCMC.py:310-340's running covariance, symmetric by construction), for chain
+// n: `d` is the chain's column of x - mean_old (LDS, rows `ds` doubles apart); member j0 of the js lanes that
+// share the chain takes columns j0, j0 + js, ... of every row (entries j0, j0 + js, ... of the triangle in the
+// second form).  Two forms of the same sums:
+//  * adds that return nothing (add_noret) - no round trips, which is what a job of few chains waits for
+//    (4096 chains x 32 parameters: 54 -> 19 us per step in the fused Cl wave kernel, 87 -> 61 in the step-wise
+//    engine); L2 retires about one such add per channel and clock, 2.3e11 entries/s measured;
+//  * load / add / store, eight loads in flight per lane - bound by bandwidth, 2.8e11 entries/s at 65 536 chains.
+// gmh_comom_atomic picks by the entries of one step (uniform over the grid).
+__device__ __forceinline__ bool gmh_comom_atomic(int64_t N, int P) {
+  return N * (P * (P + 1) / 2) <= kComomAtomicMaxEntries;
+}
+__device__ __forceinline__ void gmh_comom_update(double* comom, int64_t N, int64_t n, int P, double cf,
+                                                 const double* d, int ds, int j0, int js) {
+  if (gmh_comom_atomic(N, P)) {
+    double* row = comom + n;
+    for (int i = 0; i < P; ++i, row += static_cast<int64_t>(P) * N) {
+      const double ci = cf * d[i * ds];
+      for (int j = j0; j <= i; j += js) add_noret(row + static_cast<int64_t>(j) * N, ci * d[j * ds]);
+    }
+    return;
+  }
+  // Branch-free batches (a branch inside makes the compiler wait for every load and store in turn): entries
+  // beyond the triangle go to the chain's entry (0, 1) - the upper triangle is never read - with increment 0.
+  const int T = P * (P + 1) / 2;
+  if (P < 2) {                                             // (no upper triangle: one entry, one lane)
+    if (j0 == 0) comom[n] = comom[n] + cf * d[0] * d[0];
+    return;
+  }
+  double* const spare = comom + N + n;
+  constexpr int U = 8;
+  for (int e0 = j0; e0 < T; e0 += js * U) {
+    double* ptr[U];
+    double inc[U], cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * js;
+      const bool in = e < T;
+      const int ec = in ? e : 0;
+      int i = static_cast<int>((sqrtf(8.0f * static_cast<float>(ec) + 1.0f) - 1.0f) * 0.5f);   // gmh_tri_decode
+      i -= (i * (i + 1) / 2 > ec) ? 1 : 0;
+      i += ((i + 1) * (i + 2) / 2 <= ec) ? 1 : 0;
+      const int j = ec - i * (i + 1) / 2;
+      double* q = comom + (static_cast<int64_t>(i) * P + j) * N + n;
+      ptr[u] = in ? q : spare;
+      const double v = cf * d[i * ds] * d[j * ds];
+      inc[u] = in ? v : 0.0;
+      cur[u] = ldas<1>(ptr[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) stas<1>(ptr[u], cur[u] + inc[u]);
+  }
+}
+
 // getNewParams (Proposal.py:127-164) + package + prior for every chain
 // (the body of k_gmh_propose for block `vblock` of the grid; k_gmh_accept_propose runs it for the next
 // step behind the accept of this one)
@@ -355,29 +409,8 @@ __device__ __forceinline__ void gmh_accept_block(GmhArgs a, int64_t vblock, doub
   if (a.comom == nullptr) return;                          // uniform over the grid
   __syncthreads();
   if (!t.valid) return;
-  // C_ij += (n-1)/n d_i d_j with d = x - mean_old, j <= i (symmetric by construction); the
-  // triangle's entries are dealt round-robin to the groups, eight loads in flight per thread
-  const int T = P * (P + 1) / 2;
-  constexpr int U = 8;
-  for (int e0 = t.grp; e0 < T; e0 += t.G * U) {
-    double* ptr[U];
-    double inc[U], cur[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * t.G;
-      ptr[u] = nullptr;
-      if (e < T) {
-        int i, j;
-        gmh_tri_decode(e, i, j);
-        ptr[u] = a.comom + (static_cast<int64_t>(i) * P + j) * N + n;
-        inc[u] = cf * d[i * t.cb + t.cl] * d[j * t.cb + t.cl];
-        cur[u] = *ptr[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ptr[u]) *ptr[u] = cur[u] + inc[u];
-  }
+  // C_ij += (n-1)/n d_i d_j with d = x - mean_old, the columns dealt round-robin to the chain's groups
+  gmh_comom_update(a.comom, N, n, P, cf, d + t.cl, t.cb, t.grp, t.G);
 }
 
 }  // namespace mi355

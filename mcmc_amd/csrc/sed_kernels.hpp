@@ -649,18 +649,26 @@ __global__ __launch_bounds__(kBlockThreads, (mh_min_waves<MODEL, FAST, EXT, G>()
     } else if constexpr (EXT) {
       if (a.comom != nullptr && writer) {                  // C_ij += (n-1)/n d_i d_j, as k_gmh_accept
         const double cf = 1.0 - rn;
-        double cur[NTRI];
+        if (a.N * NTRI <= kComomAtomicMaxEntries) {            // few chains: adds that return nothing (gmh_comom_update)
 #pragma unroll
-        for (int i = 0; i < P; ++i)
+          for (int i = 0; i < P; ++i)
 #pragma unroll
-          for (int j = 0; j <= i; ++j)
-            cur[i * (i + 1) / 2 + j] = a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n];
+            for (int j = 0; j <= i; ++j)
+              add_noret(a.comom + (static_cast<int64_t>(i) * P + j) * a.N + n, cf * dl[i] * dl[j]);
+        } else {
+          double cur[NTRI];
 #pragma unroll
-        for (int i = 0; i < P; ++i)
+          for (int i = 0; i < P; ++i)
 #pragma unroll
-          for (int j = 0; j <= i; ++j)
-            a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n] =
-                cur[i * (i + 1) / 2 + j] + cf * dl[i] * dl[j];
+            for (int j = 0; j <= i; ++j)
+              cur[i * (i + 1) / 2 + j] = a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n];
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+              a.comom[(static_cast<int64_t>(i) * P + j) * a.N + n] =
+                  cur[i * (i + 1) / 2 + j] + cf * dl[i] * dl[j];
+        }
       }
     }
 #endif

@@ -301,7 +301,7 @@ class Engine:
     def mh_set_fused(self, on=True):
         """one-launch runs of step-wise problems where a fused kernel exists (binnedCl); on by
         default, off forces the launch-per-step engine (mi355_mh_set_fused)"""
-        check(self.lib.mi355_mh_set_fused(self._h, 1 if on else 0))
+        check(self.lib.mi355_mh_set_fused(self._h, 2 if on == "always" else (1 if on else 0)))
 
     @property
     def mh_fused_active(self):

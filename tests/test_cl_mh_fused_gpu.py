@@ -84,7 +84,7 @@ def run(kind, fused, mode, C, track_cov, inject=None, seed=97):
     block = mode != "corr_all"
     out = {}
     with Engine(seed=seed) as eng:
-        eng.mh_set_fused(fused)
+        eng.mh_set_fused("always" if fused else False)    # (these tests hold the kernels, not the size policy)
         eng.cl_load(data)
         eng.cl_set_binning(model.bins, model.shapefun)
         eng.mh_init_problem("cl", C, truth, np.full(P, 0.02), param_blocks=np.arange(P) if block else None,
@@ -188,3 +188,32 @@ def test_problems_beyond_the_fused_kernels_fall_back_to_the_stepwise_engine():
         assert not eng.mh_fused_active
         eng.mh_run(40)
         assert np.all(np.isfinite(eng.mh_moments()["lnPr"]))
+
+
+def test_the_11x11_grid_runs_fused_where_that_is_the_faster_path():
+    """The full calibration x beam grid (ClData_CosmoMC.py:317-372): 121 forms per chain and step.  The fused
+    wave kernel holds a 16-chain tile on one CU; the step-wise engine's batched form spreads the rows over the
+    chip.  Measured crossovers (cl_mhw_plan): fused from 2049 to 8192 chains, step-wise outside; "always"
+    overrides; the 11-point grids stay fused at every size."""
+    import os
+    from oracle import refcl as RC
+    from mcmc_amd import Engine
+    if os.environ.get("MI355_CLMH_WAVE"):
+        pytest.skip("MI355_CLMH_WAVE overrides the policy this test pins")
+    model, d, truth = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.02, lmax=700, seed=5)
+    model11, d11, truth11 = RC.synth_cl_problem(nb=24, npar=6, calib=0.05, beam=0.0, lmax=700, seed=5)
+    with Engine(seed=1) as eng:
+        eng.cl_load([d])
+        eng.cl_set_binning(model.bins, model.shapefun)
+        for C, want in ((40, False), (2048, False), (4096, True), (8192, True), (16384, False)):
+            eng.mh_init_problem("cl", C, truth, np.full(6, 0.02), param_blocks=np.arange(6))
+            assert eng.mh_fused_active == want, C
+        eng.mh_set_fused("always")
+        eng.mh_init_problem("cl", 40, truth, np.full(6, 0.02), param_blocks=np.arange(6))
+        assert eng.mh_fused_active
+        eng.mh_set_fused(True)
+        eng.cl_load([d11])
+        eng.cl_set_binning(model11.bins, model11.shapefun)
+        for C in (40, 4096, 65536):
+            eng.mh_init_problem("cl", C, truth11, np.full(6, 0.02), param_blocks=np.arange(6))
+            assert eng.mh_fused_active, C

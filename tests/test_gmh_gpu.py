@@ -100,7 +100,7 @@ def test_cl_reference_chain_on_the_11x11_grid(fused):
     P = model.nparam
     k = g["grid121__k"]
     with eng:
-        eng.mh_set_fused(fused)
+        eng.mh_set_fused("always" if fused else False)    # (one chain: the size policy would pick the step-wise engine)
         eng.mh_init_problem("cl", 1, g["grid121__c0_samples"][0], np.full(P, 0.05), param_blocks=np.arange(P),
                             randomize_start=False)
         assert eng.mh_fused_active == fused

@@ -16,7 +16,11 @@ with Engine(seed=1) as e:
     e.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                       randomize_start=True, track_cov=True)
     assert e.mh_fused_active
-    e.mh_run(1000)
+    e.mh_run(200)
+    e.mh_run(200)
+    print("first stage (block proposals, general instantiation, co-moments in memory): %.2f ms per 200 steps"
+          % e.last_kernel_ms, flush=True)
+    e.mh_run(600)
     e.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
     for cov in (True, False):
         e.mh_track_cov(cov)
