@@ -405,7 +405,8 @@ int mi355_rhat(mi355_ctx* ctx, double* rhat);
  * mi355_rhat_finish_async).  The library does not link RCCL: it binds ncclAllReduce from the RCCL the
  * process has loaded (the caller's own, or torch's), else from librccl.so on the loader path, and fails
  * with an error if there is none.  mcmc_amd.distributed.engine_rhat does the same through
- * torch.distributed. */
+ * torch.distributed.  rccl_comm may be NULL when this rank holds every chain (Ctot = its C): the same
+ * four kernels without a collective - mi355_rhat with the result left on the device. */
 int mi355_rhat_allreduce_async(mi355_ctx* ctx, void* rccl_comm, int64_t Ctot, double* rhat_dev);
 /* mi355_rhat for callers that cannot allocate.  It has no counterpart in the reference; it is for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same

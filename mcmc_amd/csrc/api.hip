@@ -1127,10 +1127,19 @@ int mi355_rhat_partial_async(mi355_ctx* c, int32_t pass, const double* gmean_dev
   MI355_REQUIRE(c->nsamp > 0, "mi355_rhat: no samples accumulated yet");
   MI355_REQUIRE(sums_dev && (pass == 0 || gmean_dev), "mi355_rhat_partial: null buffer");
   MI355_HIP(hipSetDevice(c->device));
-  const int64_t waves = c->mhS * c->mhP;
-  hipLaunchKernelGGL(k_rhat_partial, dim3(static_cast<unsigned>(ceil_div(waves * 64, kBlockThreads))),
-                     dim3(kBlockThreads), 0, c->stream, pass, c->mhP, c->mhS, c->C, c->N,
-                     1.0 / static_cast<double>(c->nsamp), c->mean.p, c->m2.p, gmean_dev, sums_dev);
+  const int lps = c->C <= 16 ? 16 : (c->C <= 32 ? 32 : 64);   // lanes per source
+  const int64_t waves = ceil_div(c->mhS, kRhatU * (64 / lps)) * c->mhP;
+  const dim3 grid(static_cast<unsigned>(ceil_div(waves * 64, kBlockThreads)));
+  const double rn = 1.0 / static_cast<double>(c->nsamp);
+  if (lps == 16)
+    hipLaunchKernelGGL(k_rhat_partial<16>, grid, dim3(kBlockThreads), 0, c->stream, pass, c->mhP, c->mhS, c->C, c->N,
+                       rn, c->mean.p, c->m2.p, gmean_dev, sums_dev);
+  else if (lps == 32)
+    hipLaunchKernelGGL(k_rhat_partial<32>, grid, dim3(kBlockThreads), 0, c->stream, pass, c->mhP, c->mhS, c->C, c->N,
+                       rn, c->mean.p, c->m2.p, gmean_dev, sums_dev);
+  else
+    hipLaunchKernelGGL(k_rhat_partial<64>, grid, dim3(kBlockThreads), 0, c->stream, pass, c->mhP, c->mhS, c->C, c->N,
+                       rn, c->mean.p, c->m2.p, gmean_dev, sums_dev);
   MI355_HIP(hipGetLastError());
   return 0;
 }
@@ -1239,11 +1248,13 @@ static rccl_allreduce_fn rccl_allreduce() {
 
 int mi355_rhat_allreduce_async(mi355_ctx* c, void* rccl_comm, int64_t Ctot, double* rhat_dev) {
   MI355_REQUIRE(c && c->mh_ready && rhat_dev, "mi355_rhat_allreduce: bad argument");
-  MI355_REQUIRE(rccl_comm, "mi355_rhat_allreduce: null communicator");
+  // (a null communicator: this rank holds every chain - the same kernels, no collective)
+  MI355_REQUIRE(rccl_comm || Ctot == c->C, "mi355_rhat_allreduce: null communicator with Ctot=%lld != the %d chains of this rank",
+                static_cast<long long>(Ctot), c->C);
   MI355_REQUIRE(Ctot >= 2 && Ctot >= c->C, "mi355_rhat_allreduce: Ctot=%lld chains per source over all ranks (this rank holds %d)",
                 static_cast<long long>(Ctot), c->C);
-  const rccl_allreduce_fn allreduce = rccl_allreduce();
-  MI355_REQUIRE(allreduce, "mi355_rhat_allreduce: no RCCL in this process (ncclAllReduce not found, librccl.so not loadable)");
+  const rccl_allreduce_fn allreduce = rccl_comm ? rccl_allreduce() : nullptr;
+  MI355_REQUIRE(!rccl_comm || allreduce, "mi355_rhat_allreduce: no RCCL in this process (ncclAllReduce not found, librccl.so not loadable)");
   MI355_HIP(hipSetDevice(c->device));
   const int64_t n = c->mhS * c->mhP;
   if (c->scratch_a.alloc(static_cast<size_t>(n) * 3)) return -2;
@@ -1252,14 +1263,14 @@ int mi355_rhat_allreduce_async(mi355_ctx* c, void* rccl_comm, int64_t Ctot, doub
   constexpr int kNcclFloat64 = 8, kNcclSum = 0;            // rccl.h: ncclFloat64, ncclSum
   int rc = mi355_rhat_partial_async(c, 0, nullptr, gmean);
   if (rc) return rc;
-  int nrc = allreduce(gmean, gmean, static_cast<size_t>(n), kNcclFloat64, kNcclSum, rccl_comm, c->stream);
+  int nrc = rccl_comm ? allreduce(gmean, gmean, static_cast<size_t>(n), kNcclFloat64, kNcclSum, rccl_comm, c->stream) : 0;
   MI355_REQUIRE(nrc == 0, "mi355_rhat_allreduce: ncclAllReduce failed with ncclResult_t %d", nrc);
   hipLaunchKernelGGL(k_scale, dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, c->stream,
                      n, 1.0 / static_cast<double>(Ctot), gmean);
   MI355_HIP(hipGetLastError());
   rc = mi355_rhat_partial_async(c, 1, gmean, sums);
   if (rc) return rc;
-  nrc = allreduce(sums, sums, static_cast<size_t>(2 * n), kNcclFloat64, kNcclSum, rccl_comm, c->stream);
+  if (rccl_comm) nrc = allreduce(sums, sums, static_cast<size_t>(2 * n), kNcclFloat64, kNcclSum, rccl_comm, c->stream);
   MI355_REQUIRE(nrc == 0, "mi355_rhat_allreduce: ncclAllReduce failed with ncclResult_t %d", nrc);
   return mi355_rhat_finish_async(c, sums, Ctot, rhat_dev);
 }

@@ -142,6 +142,30 @@ __device__ __forceinline__ void add_noret(double* p, double v) {
   }
 }
 
+// Sum of x over the 64 lanes of the wave, valid in lane 63 (wave_sum_last<64>): six data-parallel-primitive steps on the vector
+// ALU (shifts by 1, 2, 4, 8 lanes within a row of 16, then lane 15 of a row broadcast to the next row, lane 31
+// to the upper half) instead of six round trips through the LDS crossbar per value (__shfl_xor is
+// ds_bpermute).  A fixed summation tree: the same bits on every run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);                          // 0.0 where the lane has no source / is masked out
+}
+// wave_sum_last<W>: the sums of the wave's groups of W = 16, 32 or 64 consecutive lanes, each valid in the last
+// lane of its group.
+template <int W>
+__device__ __forceinline__ double wave_sum_last(double x) {
+  static_assert(W == 16 || W == 32 || W == 64, "groups of 16, 32 or 64 lanes");
+  x += dpp_shifted<0x111, 0xf>(x);                          // row_shr:1
+  x += dpp_shifted<0x112, 0xf>(x);                          // row_shr:2
+  x += dpp_shifted<0x114, 0xf>(x);                          // row_shr:4
+  x += dpp_shifted<0x118, 0xf>(x);                          // row_shr:8   lane 15 of each row: the row's sum
+  if constexpr (W >= 32) x += dpp_shifted<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+  if constexpr (W == 64) x += dpp_shifted<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
 // Co-moment entries of one step (chains x P (P + 1) / 2) up to which the running co-moments are kept with
 // add_noret; beyond, with loads and stores (gmh_comom_update in gmh_device.hpp has the measurements).
 #ifndef MI355_COMOM_ATOMIC_MAX

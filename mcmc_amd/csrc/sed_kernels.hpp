@@ -953,39 +953,68 @@ __global__ void k_transpose(const double* __restrict__ in, double* __restrict__ 
 }
 
 // ---- Gelman-Rubin partial sums (convergence.py:71-85) ---------------------------------------
-// one wave per (source, parameter): lanes stride over the source's C chains
+// A wave serves kRhatU consecutive sources of one parameter: lanes stride over a source's C chains, the loads of
+// the kRhatU sources are issued together (a wave with one 512-byte load in flight per pass left the kernel at
+// 4 TB/s), each source's lane-strided partial sums are added on the vector ALU (wave_sum_lane63; the xor tree
+// through the LDS crossbar - 24 ds_bpermute per pair of sums - was what bounded the kernel).  Sources beyond S
+// are read as source S - 1 and not written.
+// LPS lanes per source (64, or 32 / 16 when a source has no more chains than that: two / four sources share a
+// load and the last steps of the sum are skipped); a wave serves kRhatU * 64 / LPS sources.
+constexpr int kRhatU = 4;
+template <int LPS>
 __global__ __launch_bounds__(kBlockThreads) void k_rhat_partial(
     int pass, int P, int64_t S, int C, int64_t N, double rn, const double* __restrict__ mean,
     const double* __restrict__ m2, const double* __restrict__ gmean, double* __restrict__ sums) {
+  constexpr int SPL = 64 / LPS;                            // sources per load
   const int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (w >= S * P) return;
-  const int64_t s = w / P;
-  const int p = static_cast<int>(w % P);
-  const double* mp = mean + p * N + s * C;
-  const double* vp = m2 + p * N + s * C;
-  double a0 = 0.0, a1 = 0.0;
-  if (pass == 0) {
-    for (int c = lane; c < C; c += 64) a0 += mp[c];
-  } else {
-    const double g = gmean[p * S + s];
-    for (int c = lane; c < C; c += 64) {
-      const double dm = mp[c] - g;
-      a0 += dm * dm;
-      a1 += vp[c] * rn;
+  const int sub = lane / LPS, c0 = lane % LPS;
+  const int64_t SG = (S + kRhatU * SPL - 1) / (kRhatU * SPL);
+  if (w >= SG * P) return;
+  const int p = static_cast<int>(w / SG);
+  const int64_t s0 = (w - p * SG) * (kRhatU * SPL) + sub;
+  int64_t su[kRhatU];
+#pragma unroll
+  for (int u = 0; u < kRhatU; ++u) su[u] = (s0 + u * SPL < S) ? s0 + u * SPL : S - 1;
+  const double* mp = mean + p * N;
+  const double* vp = m2 + p * N;
+  double a0[kRhatU], a1[kRhatU], g[kRhatU];
+#pragma unroll
+  for (int u = 0; u < kRhatU; ++u) {
+    a0[u] = 0.0;
+    a1[u] = 0.0;
+    g[u] = (pass == 0) ? 0.0 : gmean[p * S + su[u]];
+  }
+  for (int c = c0; c < C; c += LPS) {
+    double m[kRhatU], v[kRhatU];
+#pragma unroll
+    for (int u = 0; u < kRhatU; ++u) m[u] = mp[su[u] * C + c];
+    if (pass != 0) {                                       // uniform
+#pragma unroll
+      for (int u = 0; u < kRhatU; ++u) v[u] = vp[su[u] * C + c];
+#pragma unroll
+      for (int u = 0; u < kRhatU; ++u) {
+        const double dm = m[u] - g[u];
+        a0[u] += dm * dm;
+        a1[u] += v[u] * rn;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kRhatU; ++u) a0[u] += m[u];
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a0 += __shfl_xor(a0, off);
-    a1 += __shfl_xor(a1, off);
+  for (int u = 0; u < kRhatU; ++u) {
+    a0[u] = wave_sum_last<LPS>(a0[u]);
+    if (pass != 0) a1[u] = wave_sum_last<LPS>(a1[u]);
   }
-  if (lane == 0) {
-    if (pass == 0) {
-      sums[p * S + s] = a0;
-    } else {
-      sums[p * S + s] = a0;
-      sums[P * S + p * S + s] = a1;
+  if (c0 == LPS - 1) {
+#pragma unroll
+    for (int u = 0; u < kRhatU; ++u) {
+      if (s0 + u * SPL < S) {
+        sums[p * S + s0 + u * SPL] = a0[u];
+        if (pass != 0) sums[P * S + p * S + s0 + u * SPL] = a1[u];
+      }
     }
   }
 }

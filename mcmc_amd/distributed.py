@@ -99,6 +99,19 @@ def engine_rhat(engine, group=None, Ctot=None, timing=None):
     if timing is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(eng_stream)
+    if not (dist.is_available() and dist.is_initialized()) and (Ctot is None or Ctot == engine.C):
+        # no process group, one rank holds every chain: the library's own four kernels on the engine's stream
+        # (no collective to run beside anything, and none of the ten elementwise launches of the general path
+        # below, which a one-rank group - MI355_DIST_FORCE - still takes)
+        out = torch.empty((engine.P, engine.S), dtype=torch.float64, device=device)
+        eng_stream.wait_stream(cur)                           # `out` comes from torch's stream
+        engine.rhat_allreduce(None, engine.C, out.data_ptr())
+        cur.wait_stream(eng_stream)
+        if timing is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(cur)
+            timing.append((ev0, ev1))
+        return out.t()
 
     def partial(pass_, gmean, out):
         eng_stream.wait_stream(cur)                           # gmean / out come from torch's stream

@@ -585,9 +585,10 @@ class Engine:
 
     def rhat_allreduce(self, rccl_comm, Ctot, rhat_ptr):
         """R-hat over the chains of all ranks of an RCCL communicator (its ncclComm_t as an integer /
-        c_void_p): result [P, S] into device memory at rhat_ptr, asynchronous on the engine's stream.
+        c_void_p; None: this rank holds every chain): result [P, S] into device memory at rhat_ptr,
+        asynchronous on the engine's stream.
         The path for callers without torch.distributed; engine_rhat (mcmc_amd.distributed) is the other."""
-        check(self.lib.mi355_rhat_allreduce_async(self._h, C.c_void_p(rccl_comm), int(Ctot), C.c_void_p(rhat_ptr)))
+        check(self.lib.mi355_rhat_allreduce_async(self._h, C.c_void_p(rccl_comm or None), int(Ctot), C.c_void_p(rhat_ptr)))
 
     def mh_ess(self):
         """Effective sample size [S, P] from the trace of the last mh_run (BDA3 11.5)."""

@@ -50,7 +50,11 @@ def test_rhat_allreduce_on_a_one_rank_communicator_equals_rhat():
             with pytest.raises(Exception, match="Ctot"):
                 eng.rhat_allreduce(comm.value, C - 1, out.data_ptr())
             with pytest.raises(Exception, match="null communicator"):
-                eng.rhat_allreduce(None, C, out.data_ptr())
+                eng.rhat_allreduce(None, 2 * C, out.data_ptr())   # chains elsewhere, and no way to reach them
+            out.zero_()
+            eng.rhat_allreduce(None, C, out.data_ptr())            # every chain is here: no collective needed
+            eng.sync()
+            assert np.array_equal(out.cpu().numpy().T, want, equal_nan=True)
         finally:
             rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
             rccl.ncclCommDestroy(comm)

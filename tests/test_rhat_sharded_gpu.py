@@ -61,3 +61,26 @@ def test_chain_sharded_rhat_kernels_equal_the_formula_over_all_chains():
     finally:
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("C", [2, 7, 16, 17, 32, 33, 64, 100, 130])
+def test_rhat_over_chain_counts_on_either_side_of_the_lane_groups(C):
+    """k_rhat_partial gives a source 16, 32 or 64 lanes by its chain count (two or four sources share a load
+    below 33 / 17 chains) and a wave several sources; source counts that do not fill the last wave.
+    Reference: MCMC/convergence.py:71-85 on the chains' means and variances."""
+    from mcmc_amd import Engine, synth
+    S, P = 203, 6
+    nu, d, sig, _ = synth.sed_catalogue(S, seed=6)
+    nb = np.full(S, nu.shape[1], np.int32)
+    with Engine(seed=0x51 + C) as e:
+        e.sed_load("M2N", nb, nu, d, sig)
+        e.mh_init(C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(P), randomize_start=True)
+        e.mh_run(150)
+        got = e.rhat()
+        mom = e.mh_moments()
+    W = mom["var"].mean(axis=1)
+    B = mom["mean"].var(axis=1, ddof=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = np.where(W > 0.0, np.sqrt((W + B) / W), np.nan)          # :81-85 (a parameter that never moved)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, equal_nan=True)
+    assert np.isfinite(got).mean() > 0.9
