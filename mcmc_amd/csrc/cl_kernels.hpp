@@ -353,11 +353,7 @@ __device__ __forceinline__ void cl_form_tile(const ClFormArgs& a, const int64_t 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        double v = part[rt][i][t];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
+        const double v = row16_xor_sum(part[rt][i][t]);    // the xor 1, 2, 4, 8 butterfly, on the vector ALU
         if (lc == 0) red[(w * TR + rt * 16 + lk + 4 * i) * 3 + t] = v;
       }
   __syncthreads();

@@ -488,8 +488,7 @@ __global__ __launch_bounds__(64 * kClMhwMaxWaves, 2) void k_cl_mh_wave(const ClM
           double b4[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const double a1 = part[h][i] + __shfl_xor(part[h][i], 16);
-            b4[i] = a1 + __shfl_xor(a1, 32);
+            b4[i] = xor32_sum(xor16_sum(part[h][i]));
           }
           const double tw = (b4[0] + b4[1]) + (b4[2] + b4[3]);
           total = (w + h == 0) ? tw : total + tw;

@@ -166,6 +166,37 @@ __device__ __forceinline__ double wave_sum_last(double x) {
   return x;
 }
 
+// The xor butterflies of __shfl_xor without the LDS crossbar, same partners, same bits:
+//  * row16_xor_sum: v + its partners at lane distance 1, 2, 4, 8 - quad permutes, then (every quad / half row
+//    being uniform by then) the mirror of a half row and of the row;
+//  * xor16_sum / xor32_sum: v + v[lane ^ 16] / v + v[lane ^ 32] by gfx950's row swaps (v_permlane16_swap /
+//    v_permlane32_swap exchange the odd rows of one register with the even rows of another).
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_xor_sum(double v) {
+  v += dpp_perm<0xB1>(v);                                  // quad_perm:[1,0,3,2]
+  v += dpp_perm<0x4E>(v);                                  // quad_perm:[2,3,0,1]
+  v += dpp_perm<0x141>(v);                                 // row_half_mirror
+  v += dpp_perm<0x140>(v);                                 // row_mirror
+  return v;
+}
+__device__ __forceinline__ double xor16_sum(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
 // Co-moment entries of one step (chains x P (P + 1) / 2) up to which the running co-moments are kept with
 // add_noret; beyond, with loads and stores (gmh_comom_update in gmh_device.hpp has the measurements).
 #ifndef MI355_COMOM_ATOMIC_MAX
