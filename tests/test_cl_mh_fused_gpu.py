@@ -217,3 +217,29 @@ def test_the_11x11_grid_runs_fused_where_that_is_the_faster_path():
         for C in (40, 4096, 65536):
             eng.mh_init_problem("cl", C, truth11, np.full(6, 0.02), param_blocks=np.arange(6))
             assert eng.mh_fused_active, C
+
+
+def test_comoment_update_forms_give_the_same_sums():
+    """The running co-moments are kept in memory by adds that return nothing while a step has at most 2^23
+    entries, by load / add / store batches beyond (gmh_comom_update).  Chain n draws from its own Philox
+    stream whatever the job's size, so the first chains of a job beyond the limit (16 400 chains x 528 entries)
+    must equal, bit for bit, the same chains run as a small job: fused wave kernel and step-wise engine."""
+    from mcmc_amd import Engine
+    model, data, truth = problem("p32")
+    P = model.nparam
+    out = {}
+    for fused in (True, False):
+        for C in (16400, 24):
+            with Engine(seed=31) as eng:
+                eng.mh_set_fused("always" if fused else False)
+                eng.cl_load(data)
+                eng.cl_set_binning(model.bins, model.shapefun)
+                eng.mh_init_problem("cl", C, truth, np.full(P, 0.02), param_blocks=np.arange(P), track_cov=True)
+                assert eng.mh_fused_active == fused
+                eng.mh_run(40)
+                eng.mh_run(23)
+                out[(fused, C)] = eng.mh_covar(normalized=False)[:, :24].copy()      # [1, C, P, P]
+    ref = out[(False, 24)]
+    for key, got in out.items():
+        assert np.array_equal(got, ref, equal_nan=True), key
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0.0

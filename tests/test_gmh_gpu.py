@@ -579,3 +579,30 @@ def test_sed_fused_extended_kernel_equals_stepwise_engine(model, mode, lane_map)
         for kk, u in items:
             v = y[kk] if isinstance(y, (dict, tuple)) else y
             assert np.array_equal(u, v, equal_nan=True), (k, kk)
+
+
+def test_sed_comoment_update_forms_give_the_same_sums():
+    """The extended SED sampler's co-moments in memory (block proposals: the general instantiation): adds that
+    return nothing for a job of few chains, loads and stores beyond 2^23 entries per step (403 200 chains x 21).
+    Chain n = s C + c has its own Philox stream: the first sources of the large job equal the same sources run
+    alone, bit for bit, through the fused kernel and through the step-wise engine."""
+    from mcmc_amd import Engine, synth
+    S, C, P = 6300, 64, 6
+    nu, d, sig, truth = synth.sed_catalogue(S, seed=17)
+    nb = np.full(S, 8, np.int32)
+    out = {}
+    for fused in (True, False):
+        for s_n in (S, 3):
+            with Engine(seed=5) as eng:
+                eng.mh_set_fused(fused)
+                eng.sed_load("M2N", nb[:s_n], nu[:s_n], d[:s_n], sig[:s_n])
+                eng.mh_init_problem("sed", C, truth[:s_n, None, :].repeat(C, axis=1), np.full(P, 0.02),
+                                    param_blocks=np.arange(P), randomize_start=False, track_cov=True)
+                assert eng.mh_fused_active == fused
+                eng.mh_run(30)
+                eng.mh_run(17)
+                out[(fused, s_n)] = eng.mh_covar(normalized=False)[:3].copy()
+    ref = out[(False, 3)]
+    for key, got in out.items():
+        assert np.array_equal(got, ref, equal_nan=True), key
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0.0
