@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "beam_kernels.hpp"
+#include "beam_mh_kernels.hpp"
 #include "problems.hpp"
 
 namespace mi355 {
@@ -150,6 +151,107 @@ int mi355_beam_lnlike_dev_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C,
 }  // extern "C"
 
 namespace mi355 {
+// k_beam_chi2_mf instead of k_beam_chi2 for this job?  (beam_chi2_partials_async has the reasons)
+static bool beam_takes_mf(const BeamProblem* p, int64_t n, int C) {
+  const int mf_mode = beam_mf_mode();
+  const int ngrp16 = (C + 15) / 16;
+  return !p->xy_per_map && mf_mode != 0 && (mf_mode == 1 || (n >= 1024 && C * 4 >= ngrp16 * 16 * 3));
+}
+
+// ---- the fused sampler (beam_mh_kernels.hpp) ----
+constexpr size_t kBeamMhLdsBudget = 150 * 1024;            // of the CU's 160 KB, static tables included
+constexpr int kBeamMhMaxChunks = 512;
+struct BeamMhPlan {
+  bool ok = false;
+  int64_t nchunk = 0, chunk = 0;
+  int nsub = 1, px_lds = 0;
+  size_t lds = 0;
+};
+static BeamMhPlan beam_mh_plan(const mi355_ctx* c) {
+  BeamMhPlan r;
+  const BeamProblem* p = c->beam;
+  if (!p || p->M <= 0 || c->mhS != p->M || c->C > kBeamCH || c->mhP != kBeamP) return r;
+  if (beam_takes_mf(p, c->N, c->C)) return r;              // another summation order: not this kernel's chains
+  beam_px_plan(c->mhS, 1, p->npix, &r.nchunk, &r.chunk);
+  if (r.nchunk > kBeamMhMaxChunks) return r;
+  // Where it is the faster path (tools/scan_beam_mh.py, us per step fused / step-wise): a block walks its map's
+  // chunks two at a time on one CU where the engine's chi-square kernel has a CU per chunk, so the fused kernel
+  // wins on maps of one or two chunks (1024 pixels, one chain: 6.7 / 10.8 on one map, 6.4 / 13.6 on 256 maps;
+  // eight chains: 12.4 / 14.6) and on jobs of some hundred maps, whose launches the engine runs one behind
+  // the other (256 maps of 4096 pixels: 14.3 / 28.0 with one chain, 33.6 / 44.1 with eight; of 16 384 pixels:
+  // 35.5 / 54.6 ... 89 / 95) - and loses on a few maps of many chunks (one 64 x 64 map, one chain: 14.6 / 11.1;
+  // 16 384 pixels: 53 / 13) and from about a thousand maps up (1024 maps x 8 chains: 38 / 25 at 256 pixels).
+  // mi355_mh_set_fused(ctx, 2) takes it wherever it serves the job.
+  if (c->mh_fused != 2) {
+    const bool small_maps = r.nchunk <= 2 && c->mhS <= 512;
+    const bool many_maps = c->mhS >= 256 && c->mhS <= 512 && p->npix <= 16384;
+    if (!small_maps && !many_maps) return r;
+  }
+  // (groups of 256 threads per block: with four the kernel's registers spill - 128 per lane - and a round of
+  // chunks takes 2.3 x as long as with two)
+  static const int max_sub = [] { const char* e = getenv("MI355_BEAM_MH_SUB"); return e ? atoi(e) : 2; }();
+  r.nsub = (r.nchunk >= 4 && max_sub >= 4) ? 4 : ((r.nchunk >= 2 && max_sub >= 2) ? 2 : 1);
+  const size_t fixed = sizeof(BeamMhLds) + kStaticTabBytes;
+  // the map's pixels in LDS when they fit and every map has a CU of its own
+  const size_t with_px = beam_mh_lds_doubles(static_cast<int>(r.nchunk), p->npix, p->sig_kind, p->xy_per_map, 1) * sizeof(double);
+  r.px_lds = (c->mhS <= 256 && with_px + fixed <= kBeamMhLdsBudget) ? 1 : 0;
+  r.lds = beam_mh_lds_doubles(static_cast<int>(r.nchunk), p->npix, p->sig_kind, p->xy_per_map, r.px_lds) * sizeof(double);
+  r.ok = r.lds + fixed <= kBeamMhLdsBudget;
+  return r;
+}
+bool beam_mh_fused_ok(const mi355_ctx* c) { return c && c->beam && beam_mh_plan(c).ok; }
+
+template <int NSUB, int NCHT>
+static int launch_beam_mh2(mi355_ctx* c, const BeamMhArgs& a, size_t lds) {
+  if (lds > 48 * 1024)
+    MI355_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_mh<NSUB, NCHT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL((k_beam_mh<NSUB, NCHT>), dim3(static_cast<unsigned>(c->mhS)), dim3(256 * NSUB), lds, c->stream, a);
+  MI355_HIP(hipGetLastError());
+  return 0;
+}
+template <int NSUB>
+static int launch_beam_mh(mi355_ctx* c, const BeamMhArgs& a, size_t lds) {
+  if (c->C == 1) return launch_beam_mh2<NSUB, 1>(c, a, lds);
+  if (c->C <= 4) return launch_beam_mh2<NSUB, 4>(c, a, lds);
+  return launch_beam_mh2<NSUB, kBeamCH>(c, a, lds);
+}
+
+int beam_mh_run(mi355_ctx* c, const GmhArgs& g, int64_t nsteps, int thin, int64_t nkeep) {
+  if (beam_ready(c, "mi355_mh_run")) return -1;
+  const BeamMhPlan plan = beam_mh_plan(c);
+  MI355_REQUIRE(plan.ok, "the fused beam sampler does not serve this job (step-wise engine only)");
+  BeamProblem* p = c->beam;
+  BeamMhArgs a{};
+  a.g = g;
+  a.b.x = p->x.p;
+  a.b.y = p->y.p;
+  a.b.xy_per_map = p->xy_per_map;
+  a.b.xyref = p->xyref.p;
+  a.b.d = p->d.p;
+  a.b.w = p->w.p;
+  a.b.w_kind = p->sig_kind;
+  a.b.npix = p->npix;
+  a.b.m0 = 0;
+  a.b.C = c->C;
+  a.b.n = c->N;
+  a.b.chunk = static_cast<int>(plan.chunk);
+  a.b.nchunk = static_cast<int>(plan.nchunk);
+  a.nsteps = nsteps;
+  a.thin = thin;
+  a.nkeep = nkeep;
+  a.px_lds = plan.px_lds;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev0, c->stream));
+  int rc;
+  if (plan.nsub == 4) rc = launch_beam_mh<4>(c, a, plan.lds);
+  else if (plan.nsub == 2) rc = launch_beam_mh<2>(c, a, plan.lds);
+  else rc = launch_beam_mh<1>(c, a, plan.lds);
+  if (rc) return rc;
+  if (!c->capturing) MI355_HIP(hipEventRecord(c->ev1, c->stream));
+  if (!c->capturing) c->ev_valid = true;
+  return 0;
+}
+
 // The chi-square kernels alone: partial[n][nchunk] (lnL = -1/2 of a row's sum in ascending order:
 // k_beam_finish, or the accept step of the Metropolis-Hastings engine itself)
 int beam_chi2_partials_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta_dev,
@@ -168,9 +270,8 @@ int beam_chi2_partials_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, co
   // and one chain is the reference's own use).  MI355_BEAM_MF: 0 never, 1 wherever the grid is shared.
   // (A value differs between the two kernels in the last bits - 1e-13 relative, summation order - so a
   // job split into launches of very different sizes is not bit-for-bit the job in one launch.)
-  const int mf_mode = beam_mf_mode();
   const int ngrp16 = (C + 15) / 16;
-  if (!p->xy_per_map && mf_mode != 0 && (mf_mode == 1 || (n >= 1024 && C * 4 >= ngrp16 * 16 * 3))) {
+  if (beam_takes_mf(p, n, C)) {
     const int64_t nunit = nm * ngrp16;
     // pixel runs per unit: about 8192 waves in all (the time is flat from 2048 to 16 384 on C5), runs
     // of at least 256 pixels

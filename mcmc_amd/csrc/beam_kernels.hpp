@@ -26,9 +26,16 @@ constexpr int kBeamNC = 12;      // constants per chain in LDS
 //  k[0..1] centre, k[2..4] Cxx, Cyy, Cxy, k[5] amplitude, k[6] offset, k[7] plane factor
 //  sqrt(1/mu/mu-1), k[8] cos(phi), k[9] sin(phi), k[10] plane flag (0: mu==1, plane is the
 //  integer 0), k[11] irregular flag (non-finite constants: use IEEE exp)
-__device__ __forceinline__ void beam_consts(const double* th, double* k) {
-  const double ang = th[4];
-  const double c = cos(ang), s = sin(ang);                           // BeamModel.py:64
+// (cs: cos / sin of the position angle th[4] and of the plane's azimuth th[8] - beam_trig -, split off so that a
+// sampler whose step leaves the angles alone can keep them: most of the constants' cost is these four calls)
+__device__ __forceinline__ void beam_trig(const double* th, double* cs) {
+  cs[0] = cos(th[4]);
+  cs[1] = sin(th[4]);
+  cs[2] = cos(th[8]);
+  cs[3] = sin(th[8]);
+}
+__device__ __forceinline__ void beam_consts_cs(const double* th, const double* cs, double* k) {
+  const double c = cs[0], s = cs[1];                                 // BeamModel.py:64
   const double s12 = th[2] * th[2], s22 = th[3] * th[3];
   const double sig2x = c * c * s12 + s * s * s22;                    // :68
   const double sig2y = s * s * s12 + c * c * s22;
@@ -45,12 +52,17 @@ __device__ __forceinline__ void beam_consts(const double* th, double* k) {
   const double mu = th[7];
   k[10] = (mu == 1.0) ? 0.0 : 1.0;                                   // planexy :150
   k[7] = sqrt(1 / mu / mu - 1);                                      // :152
-  k[8] = cos(th[8]);
-  k[9] = sin(th[8]);
+  k[8] = cs[2];
+  k[9] = cs[3];
   double chk = 0.0;
   for (int i = 0; i < 7; ++i) chk += fabs(k[i]);
   if (k[10] != 0.0) chk += fabs(k[7]) + fabs(k[8]) + fabs(k[9]);
   k[11] = (chk < __builtin_inf()) ? 0.0 : 1.0;
+}
+__device__ __forceinline__ void beam_consts(const double* th, double* k) {
+  double cs[4];
+  beam_trig(th, cs);
+  beam_consts_cs(th, cs, k);
 }
 
 // model value at one point, reference operation order (OffsetNormalizedBeamModel.py:78-82)
@@ -165,6 +177,48 @@ struct BeamBlockLds {
   double red[4][kBeamCH];
 };
 
+// The constants of one chain from its parameters `th` (packaged here) into slot `slot` of the block's LDS
+// tables; an inactive slot gets the constants of a zero vector (the pixel loop reads whole groups of slots).
+// ref: the map's reference point and half extents (xr, yr, hx, hy).
+// trig (optional, LDS, 6 doubles of the slot's own): the angles of the last call and their cos / sin, reused
+// while the angles are the same bits.
+__device__ __forceinline__ void beam_chain_consts(double* th, bool active, const double* ref,
+                                                  double (*kc)[kBeamNC], double (*fc)[kBeamNF], int slot,
+                                                  double* trig = nullptr) {
+  double k[kBeamNC];
+  if (active) {
+    beam_package(th);
+    if (trig == nullptr) {
+      beam_consts(th, k);
+    } else {
+      double cs[4];
+      if (__double_as_longlong(th[4]) == __double_as_longlong(trig[0]) &&
+          __double_as_longlong(th[8]) == __double_as_longlong(trig[1])) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[i] = trig[2 + i];
+      } else {
+        beam_trig(th, cs);
+        trig[0] = th[4];
+        trig[1] = th[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) trig[2 + i] = cs[i];
+      }
+      beam_consts_cs(th, cs, k);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kBeamNC; ++i) k[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < kBeamNC; ++i) kc[slot][i] = k[i];
+  double f[kBeamNF];
+  beam_fold(k, ref[0], ref[1], f);
+  if (active && !beam_form_ok(f, ref[2], ref[3])) k[11] = 1.0;   // (kc[.][11] is written below)
+#pragma unroll
+  for (int i = 0; i < kBeamNF; ++i) fc[slot][i] = f[i];
+  kc[slot][11] = k[11];
+}
+
 // the constants of chain group `grp` of map `ml` (of this call) into LDS: threads 0 .. 7; the caller
 // puts a barrier behind it
 __device__ __forceinline__ void beam_group_consts(const BeamArgs& a, int64_t ml, int grp, BeamBlockLds& L) {
@@ -174,27 +228,105 @@ __device__ __forceinline__ void beam_group_consts(const BeamArgs& a, int64_t ml,
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
   const double* ref = a.xyref + (a.xy_per_map ? m : 0) * 4;
-  const double xr = ref[0], yr = ref[1];
   double th[kBeamP];
-  double k[kBeamNC];
   if (tid < nch) {
     const int64_t e = ml * a.C + c0 + tid;
 #pragma unroll
     for (int i = 0; i < kBeamP; ++i) th[i] = a.theta[i * a.n + e];
-    beam_package(th);
-    beam_consts(th, k);
-  } else {
+  }
+  beam_chain_consts(th, tid < nch, ref, L.kc, L.fc, tid);
+}
+
+// A thread's partial chi-squares of the pixels p0 + vt, p0 + vt + 256, ... < p1 of one map for the nch chains
+// whose constants are in (kc, fc): acc[c] (zeroed here).  vt: the thread's index among the 256 of its chunk.
+struct BeamPixels {
+  const double* xs;       // the map's coordinates, data and weights (w_kind 2: per pixel, else one value)
+  const double* ys;
+  const double* ds;
+  const double* ws;
+  int w_kind;
+  double w_shared;        // the one weight of the map (w_kind 0 / 1), read once by the caller
+  double xr, yr;          // reference point of the map's coordinates
+};
+// The same sums in the reference's operation order, for blocks with a chain whose folded form does not apply
+// (rare).  beam_chunk_sums_exact_fn: as a function of its own, for callers on whose registers its eight inlined
+// exponentials must not weigh (the fused sampler).
+__device__ __forceinline__ void beam_chunk_sums_exact(const BeamPixels& px, int64_t p0, int64_t p1, int vt,
+                                                      const double (*kc)[kBeamNC], double w_shared, double* acc) {
+  for (int64_t p = p0 + vt; p < p1; p += 256) {
+    const double x = px.xs[p], y = px.ys[p], dv = px.ds[p];
+    const double w = (px.w_kind == 2) ? px.ws[p] : w_shared;
 #pragma unroll
-    for (int i = 0; i < kBeamNC; ++i) k[i] = 0.0;
+    for (int c = 0; c < kBeamCH; ++c) {
+      const double r = dv - beam_model_at<true>(kc[c], x, y);
+      acc[c] += (r * w) * r;
+    }
+  }
+}
+__device__ __noinline__ void beam_chunk_sums_exact_fn(const BeamPixels& px, int64_t p0, int64_t p1, int vt,
+                                                      const double (*kc)[kBeamNC], double w_shared, double* acc) {
+  beam_chunk_sums_exact(px, p0, p1, vt, kc, w_shared, acc);
+}
+// NCHT: 0 - the instantiation of the pixel loop (1 / up to 4 / up to 8 chains) is picked here; 1, 4, 8 - by the caller.
+// AS: address space of the pixel arrays (0: as the pointers say; 1 global, 3 LDS for a caller whose pointers are
+// generic - a flat load counts as an LDS operation too and would be waited for with every read of the constants).
+template <int NCHT = 0, bool EXACT_CALL = false, int AS = 0>
+__device__ __forceinline__ void beam_chunk_sums(const BeamPixels& px, int64_t p0, int64_t p1, int nch, int vt,
+                                                const double (*kc)[kBeamNC], const double (*fc)[kBeamNF],
+                                                const double* e2t, double* acc) {
+  const double* xs = px.xs;
+  const double* ys = px.ys;
+  const double* ds = px.ds;
+  const double* ws = px.ws;
+  const double xr = px.xr, yr = px.yr;
+  bool irregular = false, plane = false;
+  for (int c = 0; c < nch; ++c) {
+    irregular = irregular || kc[c][11] != 0.0;
+    plane = plane || kc[c][10] != 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < kBeamNC; ++i) L.kc[tid][i] = k[i];
-  double f[kBeamNF];
-  beam_fold(k, xr, yr, f);
-  if (tid < nch && !beam_form_ok(f, ref[2], ref[3])) k[11] = 1.0;   // (kc[.][11] is written below)
+  for (int c = 0; c < kBeamCH; ++c) acc[c] = 0.0;
+  const double w_shared = px.w_shared;
+  if (!irregular) {
+    // instantiations of one loop: per-pixel weights or one weight taken out of the sum
+    // (GaussianData.py:47), with or without a plane in any chain of the block, 1 / up to 4 / up to 8 chains
+    // (fetching a pixel an iteration ahead was measured and is no faster: two waves per SIMD cover
+    // the loads already)
+    auto pixels = [&](auto wpix, auto pl, auto nc) {
+      constexpr bool WP = decltype(wpix)::value;
+      for (int64_t p = p0 + vt; p < p1; p += 256)
+        beam_pixel_fast<WP, decltype(pl)::value, decltype(nc)::value>(fc, e2t, ldas<AS>(xs + p) - xr, ldas<AS>(ys + p) - yr,
+                                                                     ldas<AS>(ds + p), WP ? ldas<AS>(ws + p) : 0.0, acc);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto by_chains = [&](auto wpix, auto pl) {
+      if constexpr (NCHT != 0) pixels(wpix, pl, std::integral_constant<int, NCHT>{});
+      else if (nch == 1) pixels(wpix, pl, std::integral_constant<int, 1>{});
+      else if (nch <= 4) pixels(wpix, pl, std::integral_constant<int, 4>{});
+      else pixels(wpix, pl, std::integral_constant<int, kBeamCH>{});
+    };
+    if (px.w_kind == 2) { if (plane) by_chains(T{}, T{}); else by_chains(T{}, F{}); }
+    else                { if (plane) by_chains(F{}, T{}); else by_chains(F{}, F{}); }
+    if (px.w_kind != 2) {
 #pragma unroll
-  for (int i = 0; i < kBeamNF; ++i) L.fc[tid][i] = f[i];
-  L.kc[tid][11] = k[11];
+      for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
+    }
+  } else {
+    if constexpr (EXACT_CALL) beam_chunk_sums_exact_fn(px, p0, p1, vt, kc, w_shared, acc);
+    else beam_chunk_sums_exact(px, p0, p1, vt, kc, w_shared, acc);
+  }
+}
+// ... their sums over the wave into red[c] (lane 0 writes); the four waves' sums of a chunk are then added
+// as ((red0 + red1) + red2) + red3
+__device__ __forceinline__ void beam_chunk_wave_sums(const double* acc, int nch, int lane, double* red) {
+#pragma unroll
+  for (int c = 0; c < kBeamCH; ++c) {
+    if (c < nch) {                                         // (uniform: a block of one chain reduces one sum)
+      const double v = wave_xor_sum_desc(acc[c]);          // the xor butterfly 32 .. 1, on the vector ALU
+      if (lane == 0) red[c] = v;
+    }
+  }
 }
 
 // pixel chunk `bx` of map `ml` for the chains of group `grp` (constants in LDS): every thread's partial
@@ -205,66 +337,20 @@ __device__ __forceinline__ void beam_chunk(const BeamArgs& a, int bx, int64_t ml
   const int64_t m = a.m0 + ml;
   const int c0 = grp * kBeamCH;
   const int nch = min(kBeamCH, a.C - c0);
-  const double xr = a.xyref[(a.xy_per_map ? m : 0) * 4], yr = a.xyref[(a.xy_per_map ? m : 0) * 4 + 1];
-  bool irregular = false, plane = false;
-  for (int c = 0; c < nch; ++c) {
-    irregular = irregular || L.kc[c][11] != 0.0;
-    plane = plane || L.kc[c][10] != 0.0;
-  }
-  const double* xs = a.x + (a.xy_per_map ? m * a.npix : 0);
-  const double* ys = a.y + (a.xy_per_map ? m * a.npix : 0);
-  const double* ds = a.d + m * a.npix;
-  const double* ws = a.w + (a.w_kind == 2 ? m * a.npix : (a.w_kind == 1 ? m : 0));
+  BeamPixels px;
+  px.xs = a.x + (a.xy_per_map ? m * a.npix : 0);
+  px.ys = a.y + (a.xy_per_map ? m * a.npix : 0);
+  px.ds = a.d + m * a.npix;
+  px.ws = a.w + (a.w_kind == 2 ? m * a.npix : (a.w_kind == 1 ? m : 0));
+  px.w_kind = a.w_kind;
+  px.w_shared = (a.w_kind == 2) ? 0.0 : px.ws[0];
+  px.xr = a.xyref[(a.xy_per_map ? m : 0) * 4];
+  px.yr = a.xyref[(a.xy_per_map ? m : 0) * 4 + 1];
   const int64_t p0 = static_cast<int64_t>(bx) * a.chunk;
   const int64_t p1 = min(p0 + a.chunk, a.npix);
   double acc[kBeamCH];
-#pragma unroll
-  for (int c = 0; c < kBeamCH; ++c) acc[c] = 0.0;
-  const double w_shared = (a.w_kind == 2) ? 0.0 : ws[0];
-  if (!irregular) {
-    // instantiations of one loop: per-pixel weights or one weight taken out of the sum
-    // (GaussianData.py:47), with or without a plane in any chain of the block, 1 / up to 4 / up to 8 chains
-    // (fetching a pixel an iteration ahead was measured and is no faster: two waves per SIMD cover
-    // the loads already)
-    auto pixels = [&](auto wpix, auto pl, auto nc) {
-      constexpr bool WP = decltype(wpix)::value;
-      for (int64_t p = p0 + tid; p < p1; p += 256)
-        beam_pixel_fast<WP, decltype(pl)::value, decltype(nc)::value>(L.fc, e2t, xs[p] - xr, ys[p] - yr, ds[p],
-                                                                     WP ? ws[p] : 0.0, acc);
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    auto by_chains = [&](auto wpix, auto pl) {
-      if (nch == 1) pixels(wpix, pl, std::integral_constant<int, 1>{});
-      else if (nch <= 4) pixels(wpix, pl, std::integral_constant<int, 4>{});
-      else pixels(wpix, pl, std::integral_constant<int, kBeamCH>{});
-    };
-    if (a.w_kind == 2) { if (plane) by_chains(T{}, T{}); else by_chains(T{}, F{}); }
-    else               { if (plane) by_chains(F{}, T{}); else by_chains(F{}, F{}); }
-    if (a.w_kind != 2) {
-#pragma unroll
-      for (int c = 0; c < kBeamCH; ++c) acc[c] *= w_shared;
-    }
-  } else {
-    for (int64_t p = p0 + tid; p < p1; p += 256) {
-      const double x = xs[p], y = ys[p], dv = ds[p];
-      const double w = (a.w_kind == 2) ? ws[p] : w_shared;
-#pragma unroll
-      for (int c = 0; c < kBeamCH; ++c) {
-        const double r = dv - beam_model_at<true>(L.kc[c], x, y);
-        acc[c] += (r * w) * r;
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < kBeamCH; ++c) {
-    if (c < nch) {                                         // (uniform: a block of one chain reduces one sum)
-      double v = acc[c];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) L.red[wv][c] = v;
-    }
-  }
+  beam_chunk_sums(px, p0, p1, nch, tid, L.kc, L.fc, e2t, acc);
+  beam_chunk_wave_sums(acc, nch, lane, L.red[wv]);
   __syncthreads();
   if (tid < nch) {
     const double s = ((L.red[0][tid] + L.red[1][tid]) + L.red[2][tid]) + L.red[3][tid];

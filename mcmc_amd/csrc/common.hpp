@@ -197,6 +197,20 @@ __device__ __forceinline__ double xor32_sum(double v) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// The whole-wave butterfly v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 (every lane ends with the sum) with the
+// operands of __shfl_xor's: row swaps for 32 and 16; then rotations within a row by 8, 4, 2, 1 - after the step
+// for distance 2 d the values repeat with period 2 d in the row, so the lane d to either side holds what lane ^ d
+// holds.
+__device__ __forceinline__ double wave_xor_sum_desc(double v) {
+  v = xor32_sum(v);
+  v = xor16_sum(v);
+  v += dpp_perm<0x128>(v);                                 // row_ror:8
+  v += dpp_perm<0x124>(v);                                 // row_ror:4
+  v += dpp_perm<0x122>(v);                                 // row_ror:2
+  v += dpp_perm<0x121>(v);                                 // row_ror:1
+  return v;
+}
+
 // Co-moment entries of one step (chains x P (P + 1) / 2) up to which the running co-moments are kept with
 // add_noret; beyond, with loads and stores (gmh_comom_update in gmh_device.hpp has the measurements).
 #ifndef MI355_COMOM_ATOMIC_MAX

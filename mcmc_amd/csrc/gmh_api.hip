@@ -122,10 +122,11 @@ static void sync_block_masks(mi355_ctx* c) {
   }
 }
 
-// one-launch path of the running sampler: 1 binnedCl kernel, 2 SED kernel, 0 launch per step
+// one-launch path of the running sampler: 1 binnedCl kernel, 2 SED kernel, 3 beam kernel, 0 launch per step
 static int fused_kind(mi355_ctx* c) {
   GmhState* g = c->gmh;
   if (!c->mh_fused) return 0;
+  if (g->pb.kind == GMH_BEAM && beam_mh_fused_ok(c)) return 3;
   if (g->pb.kind == GMH_CL && cl_mh_fused_nw(c, g->pb.P, c->nblock, c->npn, g->cov_on ? 1 : 0) > 0) return 1;
   if (g->pb.kind == GMH_SED && sed_mh_fused_ok(c)) return 2;
   return 0;
@@ -286,8 +287,8 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
     if (c->tr_theta.alloc(rows * P) || c->tr_lnPr.alloc(rows) || c->tr_acc.alloc(rows)) return -2;
   }
   const int fused = fused_kind(c);
-  if (fused == 1) {
-    // binnedCl: the whole run in one launch of the fused kernel (cl_mh_kernels.hpp)
+  if (fused == 1 || fused == 3) {
+    // binnedCl / beam: the whole run in one launch of the fused kernel (cl_mh_kernels.hpp, beam_mh_kernels.hpp)
     GmhArgs a = base_args(c);
     a.blk = c->nblock ? static_cast<int>(c->stage_step % c->nblock) : 0;
     a.step = c->step_total;
@@ -301,7 +302,8 @@ int gmh_run(mi355_ctx* c, int64_t nsteps, int32_t thin, const double* inj_n, con
       a.tr_lnPr = c->tr_lnPr.p;
       a.tr_acc = c->tr_acc.p;
     }
-    const int rc = cl_mh_run(c, a, nsteps, c->nkeep > 0 ? thin : 0, c->nkeep);
+    const int rc = fused == 1 ? cl_mh_run(c, a, nsteps, c->nkeep > 0 ? thin : 0, c->nkeep)
+                              : beam_mh_run(c, a, nsteps, c->nkeep > 0 ? thin : 0, c->nkeep);
     if (rc) return rc;
     c->step_total += nsteps;
     c->stage_step += nsteps;

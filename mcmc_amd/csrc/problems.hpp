@@ -23,5 +23,10 @@ int beam_problem_info(const mi355_ctx* c, int64_t* M, BeamPriorBox* box);
 // [nm * C][nchunk] on the device (the engine's accept step adds a row up itself: GmhArgs::lnl_partial)
 int beam_chi2_partials_async(mi355_ctx* c, int64_t m0, int64_t nm, int32_t C, const double* theta_dev,
                              const double** partial_out, int* nchunk_out);
+// BeamFit: the fused Metropolis-Hastings kernel (beam_mh_kernels.hpp), one block per map.  beam_mh_fused_ok:
+// it serves the chains of the context (at most 8 chains per map, a job the chi-square of which the step-wise
+// engine runs through k_beam_chi2, chunk sums that fit LDS).  beam_mh_run: as cl_mh_run.
+bool beam_mh_fused_ok(const mi355_ctx* c);
+int beam_mh_run(mi355_ctx* c, const GmhArgs& a, int64_t nsteps, int thin, int64_t nkeep);
 
 }  // namespace mi355

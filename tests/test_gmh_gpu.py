@@ -117,17 +117,22 @@ def test_cl_reference_chain_on_the_11x11_grid(fused):
         assert np.array_equal(mom["accept"][0, 0], g["grid121__accept0"])
 
 
-def test_beam_reference_chains():
+@pytest.mark.parametrize("fused", [False, True])
+def test_beam_reference_chains(fused):
+    """The reference's own chains on a 64 x 64 beam map, draw for draw, through the launch-per-step engine and
+    through the fused beam sampler (csrc/beam_mh_kernels.hpp)."""
     from mcmc_amd import Engine
     g = load("beam_g6.npz")
     k = g["chain__k"]
     sig = g["m64a__sig"]
     with Engine() as eng:
+        eng.mh_set_fused("always" if fused else False)
         eng.beam_load(g["m64a__x"], g["m64a__y"], g["m64a__d"], sig[0], center_min=g["centerMin"],
                       center_max=g["centerMax"], sig_min=float(g["sigMin"]), sig_max=float(g["sigMax"]))
         blocks = np.arange(7)                      # ProcessBeamData.py:215-216 (mu, phi in no block)
         eng.mh_init_problem("beam", 1, g["chain__c0_samples"][0], g["chain__sigmas"],
                             param_blocks=blocks, randomize_start=False, track_cov=True)
+        assert eng.mh_fused_active == fused
         mom = replay(eng, g, "c0", k[0], 500, 9)
         assert np.array_equal(mom["accept"][0, 0], g["chain__c0_accept"])
         covn = eng.mh_covar(normalized=True)[0, 0]
