@@ -342,7 +342,9 @@ int mi355_mh_init_problem(mi355_ctx* ctx, int32_t problem, int32_t C, const doub
  * MCMC.py:225-286 - proposal of any mode, band powers, MFMA quadratic form, marginalisation,
  * accept, moments - inside it, chain state on chip.  A SED problem on a catalogue that passed the
  * fast-path check of mi355_sed_load runs in the fused SED kernel of mi355_mh_init, extended by the
- * correlated and rotated proposals (Proposal.py:145-154) and the co-moments.  Same draws, same
+ * correlated and rotated proposals (Proposal.py:145-154) and the co-moments.  Beam chains of at most 8 chains
+ * per map run in a fused kernel of their own (a block per map) where that is the faster path: maps of up to
+ * 1024 pixels, jobs of some hundred maps.  Same draws, same
  * arithmetic, same chains as the step-wise launches, bit for bit.  on=0 forces the step-wise
  * launches; on=1 (default) takes the one-launch path where it is the faster one (the full 11 x 11 grid
  * runs fused between 2049 and 8192 chains and step-wise outside); on=2 takes it wherever a fused kernel
