@@ -18,6 +18,7 @@
 namespace mi355 {
 
 constexpr int kBeamMhMaxSub = 4;
+constexpr int kBeamMhU = 2;                 // chunks a group of 256 threads takes between two barriers
 constexpr int kBeamTri = kBeamP * (kBeamP + 1) / 2;
 
 struct BeamMhArgs {
@@ -41,7 +42,7 @@ __host__ __device__ inline size_t beam_mh_lds_doubles(int nchunk, int64_t npix, 
 struct BeamMhLds {
   double kc[kBeamCH][kBeamNC];
   double fc[kBeamCH][kBeamNF];
-  double red[2][kBeamMhMaxSub][4][kBeamCH];
+  double red[2][kBeamMhMaxSub][kBeamMhU][4][kBeamCH];
   double th[kBeamCH][kBeamP], thn[kBeamCH][kBeamP], sg[kBeamCH][kBeamP], mu[kBeamCH][kBeamP], m2[kBeamCH][kBeamP];
   double z[kBeamCH][kBeamP], dl[kBeamCH][kBeamP];
   double lnpr[kBeamCH], prior[kBeamCH], ref[4];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256 * NSUB) void k_beam_mh(BeamMhArgs a) {
   __syncthreads();
 
   const bool inject = g.inj_n != nullptr;
-  const int rounds = (b.nchunk + NSUB - 1) / NSUB;
+  const int rounds = (b.nchunk + NSUB * kBeamMhU - 1) / (NSUB * kBeamMhU);
   int blk = g.blk;
   int thin_ctr = 0;
   int64_t row_next = 0;
@@ -240,18 +241,24 @@ __global__ __launch_bounds__(256 * NSUB) void k_beam_mh(BeamMhArgs a) {
 
     // ---- chi-square: the step-wise engine's chunks, NSUB at a time ----
     for (int r = 0; r < rounds; ++r) {
-      const int bx = r * NSUB + q;
-      const bool live = bx < b.nchunk;
-      if (live) {
-        const int64_t p0 = static_cast<int64_t>(bx) * b.chunk;
-        const int64_t p1 = min(p0 + b.chunk, b.npix);
-        if (a.px_lds) beam_mh_chunk<NCHT, 3>(px, p0, p1, C, vt, S.kc, S.fc, e2t, lane, S.red[r & 1][q][wv]);
-        else beam_mh_chunk<NCHT, 1>(px, p0, p1, C, vt, S.kc, S.fc, e2t, lane, S.red[r & 1][q][wv]);
+#pragma unroll
+      for (int u = 0; u < kBeamMhU; ++u) {
+        const int bx = (r * kBeamMhU + u) * NSUB + q;
+        if (bx < b.nchunk) {
+          const int64_t p0 = static_cast<int64_t>(bx) * b.chunk;
+          const int64_t p1 = min(p0 + b.chunk, b.npix);
+          if (a.px_lds) beam_mh_chunk<NCHT, 3>(px, p0, p1, C, vt, S.kc, S.fc, e2t, lane, S.red[r & 1][q][u][wv]);
+          else beam_mh_chunk<NCHT, 1>(px, p0, p1, C, vt, S.kc, S.fc, e2t, lane, S.red[r & 1][q][u][wv]);
+        }
       }
       __syncthreads();
-      if (live && vt < C) {
-        const double (*rd)[kBeamCH] = S.red[r & 1][q];
-        part[bx * kBeamCH + vt] = ((rd[0][vt] + rd[1][vt]) + rd[2][vt]) + rd[3][vt];
+      if (vt < kBeamMhU * kBeamCH) {
+        const int u = vt / kBeamCH, c = vt % kBeamCH;
+        const int bx = (r * kBeamMhU + u) * NSUB + q;
+        if (bx < b.nchunk && c < C) {
+          const double (*rd)[kBeamCH] = S.red[r & 1][q][u];
+          part[bx * kBeamCH + c] = ((rd[0][c] + rd[1][c]) + rd[2][c]) + rd[3][c];
+        }
       }
     }
     __syncthreads();
