@@ -124,6 +124,15 @@ def cpu_vectorised(seconds=3.0):
                                      "sample": "the same in %d processes on distinct sources" % cores}}
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """one line per phase on stderr (rank 0): a long run is seen to be alive, and a stall names its phase"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +161,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     args = ap.parse_args()
+    if os.environ.get("MI355_BENCH_WATCHDOG"):               # seconds: dump every thread's Python stack, repeatedly
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MI355_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     config = args.config if args.config != "auto" else ("C2" if world_env == 1 else "C3")
     args.sources = args.sources or (100000 if config == "C2" else 1000000)
@@ -161,6 +173,7 @@ def main():
     # process initialises the GPU.  N=1 only (rank 0 of a single-process run).
     cpu = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        progress("CPU baselines (oracle port on the host cores)")
         cpu = cpu_baseline(args.sources, args.cpu_seconds)
 
     # stdout carries exactly one JSON line: libraries that write to file descriptor 1 (RCCL prints
@@ -184,6 +197,7 @@ def main():
     device = torch.device("cuda", local)
 
     S, C, inner = args.sources, args.chains, args.inner
+    progress("rank %d of %d on cuda:%d: %s, %d sources x %d chains" % (rank, world, local, config, S, C))
     nu, d, sig, _ = synth.sed_catalogue(S)                    # same sources on every rank
     nb = np.full(S, nu.shape[1], np.int32)
     eng = Engine(device=local, seed=0x5EDC0FFEE + 7919 * rank)  # distinct chains per rank
@@ -194,6 +208,7 @@ def main():
     # (run as launches of `inner` steps like the timed ones, so that every k_mh_run launch of a
     # profile of this command does the same work and rocprofv3's per-kernel average is the figure
     # the roofline uses)
+    progress("catalogue resident, chains started; %d adaptation steps" % args.adapt)
     if args.adapt > 0:
         left = args.adapt
         while left > 0:
@@ -205,8 +220,8 @@ def main():
 
     def one_step():
         eng.mh_run(inner)                                     # synchronous: the launch has finished
-        # two kernels (+ two all-reduces on several GPUs), enqueued without a host wait: the next
-        # launch starts behind the second kernel, beside the second all-reduce
+        # four small kernels (+ two all-reduces on several GPUs), enqueued without a host wait; the next
+        # launch is enqueued at once and starts behind the last of them
         return D.engine_rhat(eng, Ctot=C * world, timing=rhat_ev)
 
     def barrier():
@@ -215,17 +230,20 @@ def main():
         eng.sync()
         torch.cuda.synchronize(device)
 
+    progress("warmup: %d launches of %d MH steps + R-hat" % (args.warmup, inner))
     for _ in range(args.warmup):
         one_step()
     kernel_ms = []
     barrier()
     del rhat_ev[:]
+    progress("timed region: %d launches" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rhat = one_step()
         kernel_ms.append(eng.last_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    progress("timed region done: %.2f ms per step" % (1e3 * elapsed / args.steps))
     rhat_ms = float(np.mean([a.elapsed_time(b) for a, b in rhat_ev])) if rhat_ev else 0.0
     if rank == 0:
         print("kernel ms per launch:", " ".join("%.2f" % v for v in kernel_ms), file=sys.stderr)
@@ -240,6 +258,7 @@ def main():
     # (which stays the full evaluation of every proposed point).
     inc_out = {}
     if args.incremental_steps > 0:
+        progress("incremental sampler leg")
         eng.mh_set_incremental(True)
         if eng.mh_incremental_active:
             eng.mh_run(inner)
@@ -285,11 +304,13 @@ def main():
         # greybodies per source), few sources converge in 10 000 steps
         rows = trace_rows()
         thin = max(1, args.ess_steps // rows)
+        progress("ESS leg, production proposal: %d steps, %d trace rows" % (args.ess_steps, rows))
         eng.mh_adapt()                                        # a stage of its own: R-hat over these steps only
         eng.mh_run(rows, thin=1)                              # allocates the trace buffers (rows kept), untimed
         barrier()
         t1 = time.perf_counter()
         eng.mh_run(args.ess_steps, thin=thin)
+        progress("ESS estimator (BDA3 on the device)")
         ess = eng.mh_ess()
         barrier()
         t_ess = time.perf_counter() - t1
@@ -317,6 +338,7 @@ def main():
         eng.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                             randomize_start=True, track_cov=True)
         if eng.mh_fused_active:
+            progress("ESS leg, correlated proposals: 18 000 adaptation steps, then %d measured" % args.corr_steps)
             barrier()
             t_ad = time.perf_counter()
             eng.mh_run(2000)                                  # stage 0: the driver's widths, doBlock
@@ -361,6 +383,7 @@ def main():
     c3_out = {}
     if args.c3_slice_steps > 0 and world == 1 and config == "C2":
         S3, C3 = 1000000, 32
+        progress("C3 slice leg: %d sources x %d chains" % (S3, C3))
         nu3, d3, sig3, _ = synth.sed_catalogue(S3)
         eng.sed_load("M2N", np.full(S3, nu3.shape[1], np.int32), nu3, d3, sig3)
         eng.mh_init(C3, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6), randomize_start=True)
@@ -425,9 +448,8 @@ def main():
         # convergence.py:77-85) after adapt + warmup + timed steps
         "rhat_lt_1p1_frac": float((torch.nan_to_num(rhat, nan=float("inf")).amax(dim=1) < 1.1).double().mean().item()),
         "rhat_allreduce_bytes": 3 * 6 * 8 * S if world > 1 else 0,
-        # R-hat of every source (kernels + collectives): from its first kernel to its result, by events.  The next
-        # launch is enqueued behind its second kernel, so its last small kernels share the GPU with that launch
-        # and finish late (0.4 ms when nothing follows): a latency, not a cost.  What a step pays for it is
+        # R-hat of every source (kernels + collectives): from its first kernel to its result, by events; the next
+        # sampler launch starts behind it.  What a step pays for it in all (host gaps included) is
         # rhat_exposed_ms_per_step = ms_per_step - the sampler kernel's own time.
         "rhat_ms_per_step": rhat_ms,
         "rhat_exposed_ms_per_step": 1e3 * elapsed / args.steps - k_ms,
@@ -440,6 +462,7 @@ def main():
     out.update(c3_out)
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
+    progress("done")
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

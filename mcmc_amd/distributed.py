@@ -47,8 +47,18 @@ def _world(group=None):
 
 
 def allreduce_sum_(t, group=None):
+    """In-place sum over the ranks of `group` (a no-op without a process group).  RCCL ("nccl") reduces
+    the device tensor in place.  gloo - the rehearsal backend for boxes with fewer GPUs than ranks - has
+    no device path of its own: torch stages such tensors through pinned host memory on pool streams, and
+    with two processes on one MI355X that staging stalled at config C3's sizes (48 / 96 MB per call), so
+    the copy to the host and back is made here, synchronously."""
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -84,14 +94,20 @@ def engine_rhat(engine, group=None, Ctot=None, timing=None):
     """R-hat of every loaded source over the chains of all ranks in `group` (chain-sharded
     layout); with one rank this equals Engine.rhat().  Ctot: chains per source over all ranks
     when every rank knows it (saves a collective and a host round trip per call; all ranks must
-    pass it or none).  Returns a [S,P] CUDA tensor.
+    pass it or none).  Returns a [S,P] CUDA tensor (a view of the [P,S] result).
 
-    Nothing here waits on the host: the engine's HIP stream (mi355_stream) and torch's current
-    stream - the one the collectives run on - wait for each other through events, and the last
-    step (sqrt((W+B)/W), convergence.py:77-85) runs on torch's stream, so the engine's stream is
-    free again after the second partial-sum kernel: the next mi355_mh_run is enqueued behind that
-    kernel and runs beside the second all-reduce.  The caller synchronises torch's stream (or uses
-    the tensor on it) before reading the result on the host.
+    Nothing here waits on the host (RCCL; the gloo rehearsal path copies through the host, see
+    allreduce_sum_): the engine's HIP stream (mi355_stream) and torch's current stream - the one the
+    collectives run on - wait for each other through events.  On the device
+    the pieces run one after the other, and the last one (sqrt((W+B)/W), convergence.py:77-85:
+    mi355_rhat_finish_async) is on the engine's stream again, so the next mi355_mh_run - which the
+    host may enqueue at once - starts behind it.  Measured on one MI355X at config C3's slice
+    (1e6 sources x 32 chains, one-rank RCCL group): letting the next sampler launch run beside the
+    second all-reduce and the last step, as this function did until late in round 3, cost the
+    sampler more (130.7 -> 139.5 ms: it shares its CUs with them) than the 1.2 ms the R-hat takes
+    by itself (132.5 ms per step in sequence, 140.8 ms side by side).
+    The caller synchronises torch's stream (or uses the tensor on it) before reading the result on
+    the host.
     timing: a list that receives (start, end) torch events around the whole computation."""
     device = torch.device("cuda", engine.device)
     cur = torch.cuda.current_stream(device)
@@ -99,35 +115,35 @@ def engine_rhat(engine, group=None, Ctot=None, timing=None):
     if timing is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(eng_stream)
-    if not (dist.is_available() and dist.is_initialized()) and (Ctot is None or Ctot == engine.C):
+    out = torch.empty((engine.P, engine.S), dtype=torch.float64, device=device)
+    multi = (dist.is_available() and dist.is_initialized()) or not (Ctot is None or Ctot == engine.C)
+    if not multi:
         # no process group, one rank holds every chain: the library's own four kernels on the engine's stream
-        # (no collective to run beside anything, and none of the ten elementwise launches of the general path
-        # below, which a one-rank group - MI355_DIST_FORCE - still takes)
-        out = torch.empty((engine.P, engine.S), dtype=torch.float64, device=device)
         eng_stream.wait_stream(cur)                           # `out` comes from torch's stream
         engine.rhat_allreduce(None, engine.C, out.data_ptr())
+    else:
+        if Ctot is None:
+            t = torch.tensor([float(engine.C)], dtype=torch.float64, device=device)
+            allreduce_sum_(t, group)
+            Ctot = int(round(float(t.item())))
+        sums = torch.empty((3, engine.P, engine.S), dtype=torch.float64, device=device)
+        s0, s1 = sums[0], sums[1:]
+        eng_stream.wait_stream(cur)                           # the buffers come from torch's stream
+        engine.rhat_partial(0, s0.data_ptr())                 # sum over this rank's chains of the chain means
         cur.wait_stream(eng_stream)
-        if timing is not None:
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record(cur)
-            timing.append((ev0, ev1))
-        return out.t()
-
-    def partial(pass_, gmean, out):
-        eng_stream.wait_stream(cur)                           # gmean / out come from torch's stream
-        engine.rhat_partial(pass_, out.data_ptr(), gmean.data_ptr() if gmean is not None else None)
-        cur.wait_stream(eng_stream)                           # ... which reads the sums after the kernel
-
-    def finish(sums, Ctot, out):
-        within = sums[1] / float(Ctot)                        # mean of the chain variances, :77
-        between = sums[0] / (float(Ctot) - 1.0)               # ddof=1 variance of the chain means, :78
-        torch.sqrt((within + between) / within, out=out)
-        out.masked_fill_(~(within > 0.0), float("nan"))       # :81-85
-
-    rhat, _ = gelman_rubin_allreduce(partial, finish, engine.C, engine.P, engine.S, device, group,
-                                     Ctot=Ctot)
+        allreduce_sum_(s0, group)
+        s0.mul_(1.0 / float(Ctot))                            # the mean over all chains, as the library's k_scale
+        eng_stream.wait_stream(cur)
+        engine.rhat_partial(1, s1.data_ptr(), s0.data_ptr())  # (sum (mean_c - gmean)^2, sum var_c), centred
+        cur.wait_stream(eng_stream)
+        allreduce_sum_(s1, group)
+        eng_stream.wait_stream(cur)
+        engine.rhat_finish(s1.data_ptr(), Ctot, out.data_ptr())
+    # torch's stream waits for the engine's: whatever reuses `sums` (freed here, an allocation of torch's
+    # stream) or reads `out` on torch's stream comes after the engine's last kernel
+    cur.wait_stream(eng_stream)
     if timing is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(cur)
         timing.append((ev0, ev1))
-    return rhat
+    return out.t()
