@@ -214,6 +214,8 @@ __device__ __forceinline__ void exp2_tab_n(const double* y, const double* tab, d
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double r = fma(T[i] * f[i], p[i], T[i]);        // T (1 + f P(f)), in [1, 2)
+    // (the exponent added into the high word by two 32-bit operations instead of v_ldexp_f64 was measured
+    // slower, 26.15 -> 27.1 ms per launch of C2: profiles/history_kernels.md)
     out[i] = ldexp(r, k[i] >> kExp2Bits);                 // v_ashrrev + v_ldexp_f64
   }
 }
@@ -276,6 +278,15 @@ __device__ __forceinline__ double div_rcp(double a, double b, double rb) {   // 
 }
 
 __device__ __forceinline__ double div_fast(double a, double b) { return div_rcp(a, b, rcp_nr(b)); }
+
+// a/b for the band terms of the SED fast path: the residual correction on the raw v_rcp_f64 (2^-26), no
+// Newton step - the quotient errs by |q| 2^-52 before its final rounding (within ~1.5 ulp) where div_fast
+// is correctly rounded almost always; two FMAs less per band: 26.15 -> 25.65 ms per 200-step launch of C2
+// (tools/ab_bench.sh, one box).  Not for SEDLikelihood2, whose 2 x 2 solve multiplies the band fluxes'
+// errors by its condition number.
+__device__ __forceinline__ double div_band(double a, double b) {
+  return div_rcp(a, b, __builtin_amdgcn_rcp(b));
+}
 
 // ---- Box-Muller kernels ------------------------------------------------------------------------
 // ln(u) for normal positive u (the Box-Muller radius only needs a few ulp): u = m 2^e with

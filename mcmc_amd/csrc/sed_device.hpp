@@ -202,7 +202,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
       double pw[2];
       exp2_tab_n<2>(z, B.e2t, pw);
       const double n = pw[0] * ae, dn = 1.0 - pw[1];
-      const double r = B.d(j) - div_fast(n, dn);
+      const double r = B.d(j) - div_band(n, dn);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
@@ -239,8 +239,8 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
       exp2_tab_n<8>(z, B.e2t, pw);
       const double n1a = pw[0] * ae1, d1a = 1.0 - pw[1], n2a = pw[2] * ae2, d2a = 1.0 - pw[3];
       const double n1b = pw[4] * ae1, d1b = 1.0 - pw[5], n2b = pw[6] * ae2, d2b = 1.0 - pw[7];
-      const double ra = B.d(j) - div_fast(fma(n1a, d2a, n2a * d1a), d1a * d2a);
-      const double rb = B.d(j + 1) - div_fast(fma(n1b, d2b, n2b * d1b), d1b * d2b);
+      const double ra = B.d(j) - div_band(fma(n1a, d2a, n2a * d1a), d1a * d2a);
+      const double rb = B.d(j + 1) - div_band(fma(n1b, d2b, n2b * d1b), d1b * d2b);
       chi2 = fma(ra * B.w(j), ra, chi2);
       chi2 = fma(rb * B.w(j + 1), rb, chi2);
     }
@@ -252,7 +252,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
       exp2_tab_n<4>(z, B.e2t, pw);
       const double n1 = pw[0] * ae1, d1 = 1.0 - pw[1];
       const double n2 = pw[2] * ae2, d2 = 1.0 - pw[3];
-      const double r = B.d(j) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
+      const double r = B.d(j) - div_band(fma(n1, d2, n2 * d1), d1 * d2);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
@@ -267,7 +267,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
     double FNiF = 0.0, FNid = 0.0;
     for (int j = 0; j < B.nb; ++j) {
       const double y = B.hnu2(j) * rT;                      // base is nu itself for this model
-      const double g = div_fast(pre * exp2_fast(fma(e3, B.lhi(j), -y)), 1.0 - exp2_fast(-y));
+      const double g = div_band(pre * exp2_fast(fma(e3, B.lhi(j), -y)), 1.0 - exp2_fast(-y));
       const double gw = g * B.w(j);
       FNiF = fma(gw, g, FNiF);
       FNid = fma(gw, B.d(j), FNid);
@@ -358,7 +358,7 @@ __device__ __forceinline__ double sed_lnlike_fast(const double* th, const Bands&
       double pw[3];
       exp2_tab_n<3>(z, B.e2t, pw);
       const double t1 = (pw[2] > 50.0) ? 1.0 : -expm1_fast<false>(-pw[2]);
-      const double r = B.d(j) - div_fast((t1 * pw[0]) * cf, 1.0 - pw[1]);
+      const double r = B.d(j) - div_band((t1 * pw[0]) * cf, 1.0 - pw[1]);
       chi2 = fma(r * B.w(j), r, chi2);
     }
     return -0.5 * chi2;
@@ -416,7 +416,7 @@ __device__ __forceinline__ double sed_lnlike_fast_cb(const double* th, const Ban
       double pw[2];
       exp2_tab_n<2>(z, B.e2t, pw);
       const double n = pw[0] * ae, dn = 1.0 - pw[1];
-      r = B.d(jb) - div_fast(n, dn);
+      r = B.d(jb) - div_band(n, dn);
       rw = r * B.w(jb);
     }
     return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
@@ -441,7 +441,7 @@ __device__ __forceinline__ double sed_lnlike_fast_cb(const double* th, const Ban
       exp2_tab_n<4>(z, B.e2t, pw);
       const double n1 = pw[0] * ae1, d1 = 1.0 - pw[1];
       const double n2 = pw[2] * ae2, d2 = 1.0 - pw[3];
-      r = B.d(jb) - div_fast(fma(n1, d2, n2 * d1), d1 * d2);
+      r = B.d(jb) - div_band(fma(n1, d2, n2 * d1), d1 * d2);
       rw = r * B.w(jb);
     }
     return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
@@ -453,7 +453,7 @@ __device__ __forceinline__ double sed_lnlike_fast_cb(const double* th, const Ban
     double g = 0.0, gw = 0.0;
     if (jb < B.nb) {
       const double y = B.hnu2(jb) * rT;
-      g = div_fast(pre * exp2_fast(fma(e3, B.lhi(jb), -y)), 1.0 - exp2_fast(-y));
+      g = div_band(pre * exp2_fast(fma(e3, B.lhi(jb), -y)), 1.0 - exp2_fast(-y));
       gw = g * B.w(jb);
     }
     cb_publish(slot, gw, g);
@@ -484,7 +484,7 @@ __device__ __forceinline__ double sed_lnlike_fast_cb(const double* th, const Ban
       double pw[3];
       exp2_tab_n<3>(z, B.e2t, pw);
       const double t1 = (pw[2] > 50.0) ? 1.0 : -expm1_fast<false>(-pw[2]);
-      r = B.d(jb) - div_fast((t1 * pw[0]) * cf, 1.0 - pw[1]);
+      r = B.d(jb) - div_band((t1 * pw[0]) * cf, 1.0 - pw[1]);
       rw = r * B.w(jb);
     }
     return -0.5 * cb_chi2_in_order(rw, r, B.nbu, slot, jb);
@@ -515,8 +515,8 @@ __device__ __forceinline__ void sed_unit_terms(double e3, double T, const Bands&
       exp2_tab_n<4>(z, B.e2t, pw);
       const double na = pw[0] * em, da = 1.0 - pw[1];
       const double nb_ = pw[2] * em, db = 1.0 - pw[3];
-      u[q] = div_fast(na, da);
-      const double ub = div_fast(nb_, db);
+      u[q] = div_band(na, da);
+      const double ub = div_band(nb_, db);
       u[q + 1] = (q + 1 < B.nb) ? ub : 0.0;
     } else {
       u[q] = 0.0;
