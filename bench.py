@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--incremental-steps", type=int, default=3,
                     help="extra launches with the opt-in incremental sampler (0 = skip)")
     ap.add_argument("--corr-steps", type=int, default=50000,
-                    help="MH steps of the correlated-proposal ESS/s measurement (one GPU only), after 18 000 "
+                    help="MH steps of the correlated-proposal ESS/s measurement, after 18 000 "
                          "steps of staged adaptation; 0 = skip")
     ap.add_argument("--c3-slice-steps", type=int, default=3,
                     help="one GPU only: launches of one GPU's slice of config C3 (1e6 sources x 32 chains) "
@@ -334,7 +334,7 @@ def main():
     # chains of most sources agree (tests/test_mixing_gpu.py has the same schedule): the ESS/s figure of
     # the line.  driver.py:173-175 itself runs noCorrelations=True, which is what `value` measures.
     corr_out = {}
-    if args.corr_steps > 0 and world == 1:
+    if args.corr_steps > 0:
         eng.mh_init_problem("sed", C, synth.M2N_START, synth.M2N_PROP_SIGMAS, param_blocks=np.arange(6),
                             randomize_start=True, track_cov=True)
         if eng.mh_fused_active:
@@ -359,15 +359,26 @@ def main():
             ess_c = eng.mh_ess()
             barrier()
             t_corr = time.perf_counter() - t3
-            summ, _ = ess_summary(ess_c, eng.rhat(), t_corr)
+            summ, conv_c = ess_summary(ess_c, eng.rhat(), t_corr)
+            if world > 1:                                     # same sources on every rank, other chains: the ESS add up
+                tot = torch.tensor([conv_c, t_corr, k_corr], dtype=torch.float64, device=device)
+                both = [torch.zeros_like(tot) for _ in range(world)]
+                torch.distributed.all_gather(both, tot)
+                t_corr = float(max(b[1].item() for b in both))
+                k_corr = float(max(b[2].item() for b in both))
+                summ["ess_per_sec"] = float(sum(b[0].item() for b in both)) / t_corr
+                summ["seconds"] = t_corr
             summ.update({"steps": args.corr_steps, "thin": thin, "adapt_steps": 18000, "adapt_seconds": t3 - t_ad,
                          "ess_per_sec_incl_adaptation": summ["ess_per_sec"] * t_corr / (t_corr + t3 - t_ad),
-                         "evals_per_s": float(S) * C * args.corr_steps / (k_corr * 1e-3),
+                         "evals_per_s": float(S) * C * world * args.corr_steps / (k_corr * 1e-3),
                          "kernel": "k_mh_run<M2N, fast, extended, Cholesky-correlated>", "kernel_ms": k_corr,
                          "kernel_ms_per_200_steps": k_corr * 200.0 / args.corr_steps,
                          "proposal": "Cholesky-correlated, all parameters per step, sigma = 0.6 stdev",
                          "note": "after 18 000 adaptation steps (two uncorrelated and two correlated stages); "
-                                 "R-hat over the moments of the measured stage incl. its trace-allocation steps"})
+                                 "R-hat over the moments of the measured stage incl. its trace-allocation steps"
+                                 + ("; on several GPUs every rank adapts and converges its own %d chains per source "
+                                    "(R-hat per rank, fractions and medians are rank 0's), ESS and evals summed over "
+                                    "the ranks" % C if world > 1 else "")})
             corr_out = {"correlated_proposals": summ, "ess_per_sec": summ["ess_per_sec"],
                         "ess_rhat_lt_1p1_frac": summ["rhat_lt_1p1_frac"],
                         "ess_note": "ESS/s of the correlated-proposal leg (see correlated_proposals), counted over "

@@ -27,13 +27,16 @@ def test_two_ranks_on_one_gpu_equal_the_union_of_chains(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C3", "--sources", str(S),
            "--chains", str(C), "--inner", str(inner), "--adapt", str(adapt), "--ess-steps", "0",
-           "--incremental-steps", "0", "--no-cpu-baseline", "--dump-rhat", dump]
+           "--incremental-steps", "0", "--corr-steps", "2000", "--no-cpu-baseline", "--dump-rhat", dump]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["workload"].startswith("C3")
     assert line["config"]["layout"].startswith("chain-sharded")
     assert line["value"] > 0 and line["rhat_allreduce_bytes"] == 3 * 6 * 8 * S
+    # the correlated-proposal ESS leg runs on every rank and its figures are gathered
+    corr = line["correlated_proposals"]
+    assert corr["steps"] == 2000 and corr["ess_per_sec"] > 0 and corr["evals_per_s"] > 0
     got = np.load(dump)                                        # [S, P] over the 2 x C chains
     # the same chains in this process: two engines with the ranks' seeds, same sequence of launches
     nu, d, sig, _ = synth.sed_catalogue(S)
