@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--corr-steps", type=int, default=50000,
                     help="MH steps of the correlated-proposal ESS/s measurement, after 18 000 "
                          "steps of staged adaptation; 0 = skip")
+    ap.add_argument("--trace-rows", type=int, default=100, help="thinned trace rows kept per chain in the ESS legs")
+    ap.add_argument("--trace-gb", type=float, default=32.0, help="cap on the trace [rows, P, N] of an ESS leg, GB")
     ap.add_argument("--c3-slice-steps", type=int, default=3,
                     help="one GPU only: launches of one GPU's slice of config C3 (1e6 sources x 32 chains) "
                          "timed after the C2 legs - the same-shape anchor of a multi-GPU run; 0 = skip")
@@ -294,8 +296,8 @@ def main():
                 "ess_per_sec_all_sources": float(np.nansum(em)) / seconds,
                 "seconds": seconds}, conv
 
-    def trace_rows():      # thinned trace rows per chain: 100, fewer when [rows, P, N] would pass 32 GB
-        return int(max(4, min(100, 32e9 // (8.0 * 6 * S * C))))
+    def trace_rows():      # thinned trace rows per chain: --trace-rows, fewer when [rows, P, N] would pass --trace-gb
+        return int(max(4, min(args.trace_rows, args.trace_gb * 1e9 // (8.0 * 6 * S * C))))
 
     prod_out = {}
     if args.ess_steps > 0:
