@@ -53,7 +53,7 @@ def allreduce_sum_(t, group=None):
     with two processes on one MI355X that staging stalled at config C3's sizes (48 / 96 MB per call), so
     the copy to the host and back is made here, synchronously."""
     if dist.is_available() and dist.is_initialized():
-        if t.is_cuda and dist.get_backend(group) == "gloo":
+        if t.is_cuda and "nccl" not in str(dist.get_backend(group)):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
             t.copy_(h)
