@@ -346,6 +346,7 @@ def main():
             eng.mh_run(2000)                                  # stage 0: the driver's widths, doBlock
             eng.mh_adapt_corr(no_correlations=True)
             eng.mh_run(4000)
+            progress("  correlated stages: 2000 + 10 000 steps")
             for n in (2000, 10000):                           # correlated stages, all parameters at once
                 eng.mh_adapt_corr(no_correlations=False, do_block=False, fac=0.6)
                 eng.mh_run(n)
@@ -355,6 +356,7 @@ def main():
             thin = max(1, args.corr_steps // rows)
             eng.mh_run(rows, thin=1)
             barrier()
+            progress("  measured stage: %d steps, %d trace rows" % (args.corr_steps, rows))
             t3 = time.perf_counter()
             eng.mh_run(args.corr_steps, thin=thin)
             k_corr = eng.last_kernel_ms
