@@ -152,9 +152,11 @@ def main():
                          "uncorrelated single-parameter blocks; 0 = skip")
     ap.add_argument("--incremental-steps", type=int, default=3,
                     help="extra launches with the opt-in incremental sampler (0 = skip)")
-    ap.add_argument("--corr-steps", type=int, default=50000,
-                    help="MH steps of the correlated-proposal ESS/s measurement, after 18 000 "
-                         "steps of staged adaptation; 0 = skip")
+    ap.add_argument("--corr-steps", type=int, default=-1,
+                    help="MH steps of the correlated-proposal ESS/s measurement, after 18 000 steps of staged "
+                         "adaptation; 0 = skip; default: 50 000 on one GPU, 0 on several (every rank can run it "
+                         "on its own chains - ask for it: it takes 70 s at config C3's 3.2e7 chains per GPU, "
+                         "three times the rest of the run)")
     ap.add_argument("--trace-rows", type=int, default=100, help="thinned trace rows kept per chain in the ESS legs")
     ap.add_argument("--trace-gb", type=float, default=32.0, help="cap on the trace [rows, P, N] of an ESS leg, GB")
     ap.add_argument("--c3-slice-steps", type=int, default=3,
@@ -168,6 +170,8 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["MI355_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     config = args.config if args.config != "auto" else ("C2" if world_env == 1 else "C3")
+    if args.corr_steps < 0:
+        args.corr_steps = 50000 if world_env == 1 else 0
     args.sources = args.sources or (100000 if config == "C2" else 1000000)
     args.chains = args.chains or (64 if config == "C2" else 32)
 
